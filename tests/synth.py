@@ -1,0 +1,130 @@
+"""Deterministic synthetic inputs shared by the golden-vector generator, the parity tests and bench.py.
+
+Everything here is numpy-only (no torch, no reference code) so that the same bytes can be regenerated on the
+GPU box, where /root/reference does not exist.  The recipes follow SURVEY.md §8(d):
+
+* selector / refiner weights: same *distributions* as the reference's init rules
+  (xavier-uniform gain 0.5 for the saliency CNN, keypoint_selector.py:38-43; unit-scale dense matrices and
+  U(-0.1, 0.1) biases for the descriptor MLP, descriptor_refiner.py:47-56) drawn from a numpy PCG64 stream,
+  with conv.2.weight scaled x8 so that saliency spans ~[0.1, 0.95];
+* tokens: N(0.5, 3^2), seed 2000+i;
+* images: clip(128 + 60*lowpass(N(0,1), sigma=12 px) + 25*N(0,1)), seed 1000+i.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+C_FEAT = 384          # ViT-S/16 embed dim (dino_backbone.py:50)
+N_PREFIX = 5          # CLS + 4 register tokens (dino_backbone.py:51,91)
+
+
+def _rng(seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _uniform(rng, shape, bound) -> np.ndarray:
+    return ((rng.random(shape) * 2.0 - 1.0) * bound).astype(np.float32)
+
+
+def _normal(rng, shape, std=1.0, mean=0.0) -> np.ndarray:
+    return (rng.standard_normal(shape) * std + mean).astype(np.float32)
+
+
+def selector_state(seed: int = 0, c_in: int = C_FEAT, hidden: int = 256, w2_scale: float = 8.0,
+                   bias_scale: float = 0.02) -> dict:
+    """state_dict of models.keypoint_selector.KeypointSelector (keys: SURVEY §8b1)."""
+    rng = _rng(10_000 + seed)
+    b1 = 0.5 * np.sqrt(6.0 / (c_in * 9 + hidden * 9))
+    b2 = 0.5 * np.sqrt(6.0 / (hidden + 1))
+    return {
+        "conv.0.weight": _uniform(rng, (hidden, c_in, 3, 3), b1),
+        "conv.0.bias": _uniform(rng, (hidden,), bias_scale),
+        "conv.2.weight": _uniform(rng, (1, hidden, 1, 1), b2) * np.float32(w2_scale),
+        "conv.2.bias": _uniform(rng, (1,), bias_scale),
+    }
+
+
+def refiner_state(seed: int = 0, c_in: int = C_FEAT, hidden: int = 384, d_out: int = 128,
+                  n_blocks: int = 2) -> dict:
+    """state_dict of models.descriptor_refiner.DescriptorRefiner (keys: SURVEY §8b1)."""
+    rng = _rng(20_000 + seed)
+    sd = {
+        "input_proj.weight": _normal(rng, (hidden, c_in), 1.0 / np.sqrt(c_in)),
+        "input_proj.bias": _uniform(rng, (hidden,), 0.1),
+    }
+    for i in range(n_blocks):
+        for nm in ("norm1", "norm2"):
+            sd[f"residual_blocks.{i}.{nm}.weight"] = (1.0 + _uniform(rng, (hidden,), 0.1)).astype(np.float32)
+            sd[f"residual_blocks.{i}.{nm}.bias"] = _uniform(rng, (hidden,), 0.05)
+        for nm in ("fc1", "fc2"):
+            sd[f"residual_blocks.{i}.{nm}.weight"] = _normal(rng, (hidden, hidden), 1.0 / np.sqrt(hidden))
+            sd[f"residual_blocks.{i}.{nm}.bias"] = _uniform(rng, (hidden,), 0.1)
+    sd["output_proj.weight"] = _normal(rng, (d_out, hidden), 1.0 / np.sqrt(hidden))
+    sd["output_proj.bias"] = _uniform(rng, (d_out,), 0.1)
+    return sd
+
+
+def tokens(frame: int, grid: int = 28, batch: int = 1) -> np.ndarray:
+    """(batch, 5 + grid*grid, 384) fp32 stand-in for timm's forward_features output (dino_backbone.py:85)."""
+    rng = _rng(2000 + frame)
+    return _normal(rng, (batch, N_PREFIX + grid * grid, C_FEAT), 3.0, 0.5)
+
+
+def token_sequence(n_frames: int, grid: int = 28, seed: int = 7, noise: float = 0.35) -> np.ndarray:
+    """(n_frames, 5+grid^2, 384): windows sliding over one larger random field plus per-frame noise, so that
+    consecutive frames share most of their content and mutual matches exist."""
+    rng = _rng(30_000 + seed)
+    pad = 6
+    field = _normal(rng, (grid + 2 * pad, grid + 2 * pad, C_FEAT), 3.0, 0.5)
+    out = np.empty((n_frames, N_PREFIX + grid * grid, C_FEAT), np.float32)
+    ox = oy = pad
+    for i in range(n_frames):
+        step = rng.integers(-1, 2, size=2)
+        ox = int(np.clip(ox + step[0], 0, 2 * pad))
+        oy = int(np.clip(oy + step[1], 0, 2 * pad))
+        win = field[oy:oy + grid, ox:ox + grid].reshape(grid * grid, C_FEAT)
+        out[i, :N_PREFIX] = _normal(rng, (N_PREFIX, C_FEAT), 3.0, 0.5)
+        out[i, N_PREFIX:] = win + _normal(rng, win.shape, noise)
+    return out
+
+
+def image(frame: int, height: int = 480, width: int = 640) -> np.ndarray:
+    """(H, W, 3) uint8 smooth-plus-texture RGB frame (SURVEY §8d pixel recipe)."""
+    from scipy.ndimage import gaussian_filter
+
+    rng = _rng(1000 + frame)
+    low = gaussian_filter(rng.standard_normal((height, width, 3)), sigma=(12, 12, 0), mode="wrap")
+    low = low / (low.std() + 1e-9)
+    img = 128.0 + 60.0 * low + 25.0 * rng.standard_normal((height, width, 3))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def image_sequence(n_frames: int, height: int = 480, width: int = 640, seed: int = 3) -> np.ndarray:
+    """(n, H, W, 3) uint8: one base frame shifted by <= 4 px per step plus fresh texture noise."""
+    rng = _rng(40_000 + seed)
+    base = image(seed, height + 64, width + 64).astype(np.int16)
+    out = np.empty((n_frames, height, width, 3), np.uint8)
+    ox = oy = 32
+    for i in range(n_frames):
+        step = rng.integers(-4, 5, size=2)
+        ox = int(np.clip(ox + step[0], 0, 64))
+        oy = int(np.clip(oy + step[1], 0, 64))
+        win = base[oy:oy + height, ox:ox + width] + rng.integers(-6, 7, size=(height, width, 3))
+        out[i] = np.clip(win, 0, 255).astype(np.uint8)
+    return out
+
+
+def depth(frame: int, height: int = 480, width: int = 640) -> np.ndarray:
+    """uint16 depth, U(2500, 25000) == 0.5-5 m at TUM scale 5000 (tum_dataset.py:139); loaded, never consumed."""
+    return _rng(5000 + frame).integers(2500, 25000, size=(height, width), dtype=np.uint16)
+
+
+def unit_descriptors(seed: int, n: int, d: int = 128, dup: int = 0) -> np.ndarray:
+    """(n, d) fp32 unit-norm rows; the last `dup` rows repeat earlier rows bit-for-bit (SURVEY H2 duplicates)."""
+    rng = _rng(50_000 + seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.sqrt((x.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32)
+    if dup:
+        src = rng.integers(0, n - dup, size=dup)
+        x[n - dup:] = x[src]
+    return x
