@@ -1,0 +1,150 @@
+/*
+ * sslam_hip.h - C ABI of libsslam_hip.so: the MI355X (gfx950) implementation of the semantic-slam per-frame
+ * feature-extraction + descriptor-matching hot path.
+ *
+ * The reference (Siverteh/semantic-slam-master) is pure Python: there is no FFI / plugin layer to mirror, so this
+ * header defines the boundary a maintainer binds with ctypes (INTEGRATION.md shows the stub).  One entry per fused
+ * stage; each cites the reference code it replaces (paths relative to the reference repo).
+ *
+ * Conventions (all entries):
+ *   - every pointer is a CALLER-OWNED DEVICE pointer unless the name ends in _host; the library never allocates,
+ *     frees or copies to the host;
+ *   - `stream` is a hipStream_t passed as void* (PyTorch: torch.cuda.current_stream().cuda_stream); calls only
+ *     enqueue work - no synchronisation, no host read-back;
+ *   - return value: SSLAM_OK or a negative SSLAM_E_* code; launch failures are reported via hipGetLastError;
+ *   - stateless and thread-safe given distinct streams / workspaces;
+ *   - all floating point is IEEE fp32 evaluated in the canonical order documented in oracle/sslam_oracle.h
+ *     (contractions = one fused-multiply-add chain in increasing k on v_mfma_f32_32x32x2_f32), so results are
+ *     bit-identical to the CPU oracle.
+ */
+#ifndef SSLAM_HIP_H
+#define SSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSLAM_OK 0
+#define SSLAM_E_INVALID (-1)     /* null pointer / non-positive size / misaligned pointer */
+#define SSLAM_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define SSLAM_E_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
+
+#define SSLAM_C 384   /* backbone embed dim (ViT-S/16), dino_backbone.py:50 */
+#define SSLAM_HID 384 /* refiner hidden dim, configs/train_config.yaml:13 */
+#define SSLAM_D 128   /* descriptor dim, configs/train_config.yaml:12 */
+
+/* library version (major*10000 + minor*100 + patch) and the gfx target it was compiled for */
+int sslam_version(void);
+const char *sslam_arch(void);
+/* number of kernel launches enqueued by this process so far (lets tests prove the HIP path ran) */
+long long sslam_launch_count(void);
+
+/* ---- weight packing (host side, plain C++; run once per checkpoint) ------------------------------------------
+ * The kernels read weights in an LDS-image order: K split into chunks, each chunk stored [n][k] with k permuted
+ * inside groups of 8 as (0,2,4,6,1,3,5,7) so that one ds_read_b128 feeds four consecutive 32x32x2 MFMA steps.
+ *
+ * sslam_pack_conv3x3_host: w (hs,384,3,3) [keypoint_selector.py:31, state_dict key conv.0.weight]
+ *                          -> out (9*384*hs floats).
+ * sslam_pack_linear_host:  w (n_out, k_in) [nn.Linear weight, descriptor_refiner.py:35,43,103,105]
+ *                          -> out (n_out*k_in floats); k_in % 16 == 0. */
+int sslam_pack_conv3x3_host(const float *w_host, int hs, float *out_host);
+int sslam_pack_linear_host(const float *w_host, int n_out, int k_in, float *out_host);
+
+/* ---- A0: preprocessing.  Replaces transforms.Compose([Resize, ToTensor, Normalize]) applied at
+ * visualize_matches_sequence.py:59-67,72 (Pillow antialiased bilinear resize, /255, ImageNet mean/std).
+ * sslam_resample_table_host builds Pillow's fixed-point coefficient table for one axis (filter 0 = bilinear,
+ * 1 = bicubic): bounds (out_size*2 int32: first input index, tap count), coefs (out_size*ksize int32);
+ * returns ksize (<= SSLAM_MAX_TAPS) or a negative error.
+ * img (n, h, w, 3) uint8 -> out (n, 3, size, size) fp32. */
+#define SSLAM_MAX_TAPS 32
+int sslam_resample_table_host(int in_size, int out_size, int filter, int32_t *bounds_host, int32_t *coefs_host,
+                              int coefs_capacity);
+int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                        const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                        int ksize_v, float *out_chw, void *stream);
+
+/* ---- A2: token drop + BatchNorm1d over tokens.  Replaces DinoBackbone.forward after the ViT call,
+ * dino_backbone.py:91-106.  tokens (n_frames, tokens_per_frame, 384); statistics over `group` consecutive frames
+ * (group = 1 reproduces per-frame B=1 calls).  train != 0: batch statistics, also written to
+ * out_mean / out_var (n_frames/group, 384; biased variance); train == 0: run_mean / run_var are used.
+ * out_feat (n_frames, cells, 384) with cells = tokens_per_frame - n_prefix. */
+int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                    const float *gamma, const float *beta, const float *run_mean, const float *run_var, int train,
+                    float eps, float *out_feat, float *out_mean, float *out_var, void *stream);
+
+/* ---- A3: saliency CNN.  Replaces KeypointSelector.forward, keypoint_selector.py:45-67
+ * (conv3x3 384->hs + ReLU + conv1x1 hs->1 + sigmoid).  feat (n_frames, G, G, 384) NHWC; w1_packed from
+ * sslam_pack_conv3x3_host; b1 (hs), w2 (hs), b2 (1); hs in {128, 256}.  sal (n_frames, G, G). */
+int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
+                            const float *w2, const float *b2, int hs, float *sal, void *stream);
+
+/* ---- A4 + A5 (+ A8): NMS + percentile threshold + branchy top-k.  Replaces KeypointSelector.select_keypoints /
+ * _apply_nms, keypoint_selector.py:69-226, and DinoBackbone.patch_to_pixel, dino_backbone.py:154-165.
+ * sal (n_frames, G, G) -> kp_xy (n_frames, K, 2) fp32 (x, y) patch units; scores (n_frames, K);
+ * idx (n_frames, K) int32 flat cell index (may be NULL); kp_pixel (n_frames, K, 2) = kp*16+8 (may be NULL);
+ * status (n_frames) int32: 0 ok, 1 = the reference's torch.topk would raise (K exceeds the cells).
+ * No host synchronisation: the whole data-dependent control flow runs on the device, one workgroup per frame.
+ * G*G <= 4096, K <= 4096, 0 <= nms_radius <= 8. */
+int sslam_select_keypoints(const float *sal, int n_frames, int G, int K, int nms_radius, double min_score_percentile,
+                           float *kp_xy, float *scores, int32_t *idx, float *kp_pixel, int32_t *status,
+                           void *stream);
+
+/* ---- A6: bilinear feature gather.  Replaces DinoBackbone.extract_at_keypoints, dino_backbone.py:114-152
+ * (grid_sample bilinear, align_corners=True, zero padding).  feat (n_frames, G, G, 384), kp_xy (n_frames, K, 2)
+ * -> out (n_frames, K, 384). */
+int sslam_gather(const float *feat, int n_frames, int G, const float *kp_xy, int K, float *out, void *stream);
+
+/* ---- A7: descriptor MLP.  Replaces DescriptorRefiner.forward / ResidualBlock.forward,
+ * descriptor_refiner.py:58-126.  Refiner weights are passed as ONE packed device buffer laid out by
+ * sslam_refiner_pack_host (offsets in floats are returned by sslam_refiner_layout).
+ * x (rows, 384) -> desc (rows, 128). */
+typedef struct {
+    int n_blocks;          /* residual blocks (num_layers - 2; 2 in the shipped config) */
+    long long total;       /* floats in the packed buffer */
+    long long in_w, in_b;  /* packed input_proj.weight, input_proj.bias */
+    long long blk[8][8];   /* per block: norm1.w, norm1.b, fc1.w(packed), fc1.b, norm2.w, norm2.b, fc2.w(packed), fc2.b */
+    long long out_w, out_b;
+} sslam_refiner_layout_t;
+int sslam_refiner_layout(int n_blocks, sslam_refiner_layout_t *layout_host);
+/* w_host: 4 + 8*n_blocks host pointers in state_dict order (see oracle/sslam_oracle.h ora_refine) */
+int sslam_refiner_pack_host(const float *const *w_host, int n_blocks, float *out_host);
+int sslam_refine(const float *x, long long rows, const float *packed, int n_blocks, float *desc, void *stream);
+
+/* ---- A6 + A7 fused: gather straight into the MLP's LDS tile (the pipeline's fast path). */
+int sslam_gather_refine(const float *feat, int n_frames, int G, const float *kp_xy, int K, const float *packed,
+                        int n_blocks, float *desc, void *stream);
+
+/* ---- A9: per-keypoint intensity.  Replaces visualize_matches_sequence.py:87-95 (Pillow BICUBIC resize to
+ * (size,size) -> "L" -> /255 -> gray[round(y), round(x)]); only the pixels that are looked up are resampled.
+ * img (n, h, w, 3) uint8; kp_pixel (n, K, 2); tables from sslam_resample_table_host(filter = 1). */
+int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                             const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                             int ksize_v, const float *kp_pixel, int K, float *out, void *stream);
+
+/* ---- M1..M5 core: cosine-similarity GEMM + row / column arg-max.  Replaces torch.mm + argmax(dim=1) +
+ * argmax(dim=0) at visualize_matches_sequence.py:144-148 (and visualize_matches.py:105-109, train.py:423-425,
+ * test/test_descriptor_quality.py:116-123, test/test_tracking.py:159-160).
+ * For each of n_pairs pairs p: d1 = desc1 + p*stride1 (n1 x 128), d2 = desc2 + p*stride2 (n2 x 128)
+ * (strides in floats; stride 0 broadcasts).  nn12/s12 (n_pairs, n1): first arg-max / max over d2 for each row of
+ * d1; nn21/s21 (n_pairs, n2): the column direction.  second12 (n_pairs, n1): the largest similarity of the row with
+ * the winner removed (-inf if n2 == 1) - what the ratio tests of visualize_matches.py:116-121 and
+ * test/test_descriptor_quality.py:129-131 need, without sorting rows.  s12 / s21 / second12 may be NULL. */
+int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2, int n2,
+                     int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12, void *stream);
+
+/* ---- M1: mutual check + thresholds + quality + ordered compaction.  Replaces
+ * SequenceMatcher.match_with_quality, visualize_matches_sequence.py:149-197, given the arg-max arrays above.
+ * scores / intensities are (n_pairs-strided) per-frame arrays like the descriptors; intensity1/2 may be NULL.
+ * Outputs per pair: matches (cap = n1 rows of 2 int64, ascending idx1), quality (n1 fp32), count (1 int32). */
+int sslam_match_finalize(const int32_t *nn12, const float *s12, const int32_t *nn21, int n1, int n2, int n_pairs,
+                         const float *scores1, long long sstride1, const float *scores2, long long sstride2,
+                         const float *intensity1, const float *intensity2, float w_desc, float w_sal,
+                         float min_saliency, float min_sim, float min_intensity, int64_t *matches, float *quality,
+                         int32_t *count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

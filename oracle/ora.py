@@ -165,6 +165,39 @@ def sim_argmax(d1, d2):
     return nn12, s12, nn21, s21
 
 
+def sim_matrix(d1, d2):
+    d1, d2 = _f32(d1), _f32(d2)
+    S = np.empty((d1.shape[0], d2.shape[0]), np.float32)
+    lib().ora_sim_matrix(_p(d1), d1.shape[0], _p(d2), d2.shape[0], d1.shape[1], _p(S))
+    return S
+
+
+def find_matches_m2(d1, d2, ratio_thresh=0.8):
+    """M2 (visualize_matches.py:102-124) on the canonical similarity matrix."""
+    S = sim_matrix(d1, d2)
+    nn12, nn21 = S.argmax(axis=1), S.argmax(axis=0)
+    out = []
+    for i in range(S.shape[0]):
+        j = nn12[i]
+        if nn21[j] == i:
+            sims = S[i].copy()
+            sims[j] = -1
+            if S[i, j] > sims.max() * np.float32(ratio_thresh):
+                out.append((i, int(j), S[i, j]))
+    return out
+
+
+def find_mnn_m4(d1, d2, ratio_threshold=0.9):
+    """M4 (test/test_descriptor_quality.py:97-142) on the canonical similarity matrix."""
+    S = sim_matrix(d1, d2)
+    nn12, nn21 = S.argmax(axis=1), S.argmax(axis=0)
+    mutual = nn21[nn12] == np.arange(S.shape[0])
+    srt = np.sort(S, axis=1)[:, ::-1]
+    ratio = srt[:, 1] / (srt[:, 0] + np.float32(1e-8))
+    idx1 = np.where(mutual & (ratio < np.float32(ratio_threshold)))[0]
+    return np.stack([idx1, nn12[idx1]], axis=1).astype(np.int64), (np.float32(1.0) - S.max(axis=1)[idx1])
+
+
 def match_with_quality(d1, d2, s1, s2, saliency_weight=0.3, min_saliency=0.2, min_descriptor_sim=0.7,
                        intensity1=None, intensity2=None, min_intensity=0.1):
     d1, d2, s1, s2 = _f32(d1), _f32(d2), _f32(s1), _f32(s2)

@@ -566,6 +566,17 @@ void ora_sim_argmax(const float *d1, int n, const float *d2, int m, int d, int32
     free(seg); free(ipart); free(cpart); free(Bt);
 }
 
+/* the full similarity matrix in the canonical order (tests of M2 / M4 derive second-best values from it) */
+void ora_sim_matrix(const float *d1, int n, const float *d2, int m, int d, float *S) {
+    float *Bt = transpose(d2, m, d);
+    const float **seg = (const float **)malloc((size_t)n * sizeof(float *));
+    for (int i = 0; i < n; i++) seg[i] = d1 + (size_t)i * d;
+    arows_t A = {seg, 1, d};
+    chain_gemm(&A, n, Bt, m, NULL, S, m);
+    free(seg);
+    free(Bt);
+}
+
 /* M1 (visualize_matches_sequence.py:106-197).  python-float thresholds meet fp32 tensors, so every comparison
  * and product is done in fp32 with the scalar rounded to fp32 first. */
 int ora_match_with_quality(const float *d1, int n, const float *d2, int m, int d, const float *sc1,

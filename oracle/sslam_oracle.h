@@ -73,6 +73,9 @@ void ora_pixel_to_patch(const float *px, int n, float *out);
 void ora_sim_argmax(const float *d1, int n, const float *d2, int m, int d, int32_t *nn12, float *s12,
                     int32_t *nn21, float *s21);
 
+/* full similarity matrix S (n, m) in the canonical chain order (for the M2 / M4 ratio-test checks) */
+void ora_sim_matrix(const float *d1, int n, const float *d2, int m, int d, float *S);
+
 /* M1 - visualize_matches_sequence.py:106-197.  intensity1/2 may be NULL.  Returns the match count; matches
  * (cap, 2) int64 ascending in idx1, quality (cap). */
 int ora_match_with_quality(const float *d1, int n, const float *d2, int m, int d, const float *sc1,

@@ -1,0 +1,116 @@
+// bn_tokens.hip - A2: drop the CLS/register tokens and apply BatchNorm1d over the (group*cells) x 384 token matrix.
+// Replaces DinoBackbone.forward after the ViT call (reference semantic-slam/models/dino_backbone.py:91-106).
+//
+// Grid (n_groups, 6): one workgroup (4 waves) owns 64 channels of one statistics group.  Lane l of wave w reads the
+// float4 at channels 4*(l&15).. of rows r = p + 16*i with p = 4*w + (l>>4): every wave-instruction is four fully
+// used 256-B row segments.  Column sums follow the canonical tree of oracle ora_bn_tokens: 16 sequential partials,
+// xor-16 / xor-32 butterfly inside the wave, then the four wave sums in order through LDS.
+// HBM-bound: reads the tokens (L2/MALL resident for the 2nd and 3rd sweep) and writes cells*384*4 B per frame.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 comb16(float4 v, float (*sh)[64], int wave, int lane) {
+    // v: this lane's partial P[4*wave + (lane>>4)] for 4 channels
+    float4 s;
+    s.x = v.x + __shfl_xor(v.x, 16); s.y = v.y + __shfl_xor(v.y, 16);
+    s.z = v.z + __shfl_xor(v.z, 16); s.w = v.w + __shfl_xor(v.w, 16);
+    s.x = s.x + __shfl_xor(s.x, 32); s.y = s.y + __shfl_xor(s.y, 32);
+    s.z = s.z + __shfl_xor(s.z, 32); s.w = s.w + __shfl_xor(s.w, 32);
+    __syncthreads();  // previous use of sh is over
+    if (lane < 16) {
+        sh[wave][4 * lane + 0] = s.x; sh[wave][4 * lane + 1] = s.y;
+        sh[wave][4 * lane + 2] = s.z; sh[wave][4 * lane + 3] = s.w;
+    }
+    __syncthreads();
+    const int c = 4 * (lane & 15);
+    float4 t;
+    t.x = ((sh[0][c + 0] + sh[1][c + 0]) + sh[2][c + 0]) + sh[3][c + 0];
+    t.y = ((sh[0][c + 1] + sh[1][c + 1]) + sh[2][c + 1]) + sh[3][c + 1];
+    t.z = ((sh[0][c + 2] + sh[1][c + 2]) + sh[2][c + 2]) + sh[3][c + 2];
+    t.w = ((sh[0][c + 3] + sh[1][c + 3]) + sh[2][c + 3]) + sh[3][c + 3];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict__ tokens, int tokens_per_frame,
+                                                         int n_prefix, int group, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta,
+                                                         const float *__restrict__ run_mean,
+                                                         const float *__restrict__ run_var, int train, float eps,
+                                                         float *__restrict__ out_feat, float *__restrict__ out_mean,
+                                                         float *__restrict__ out_var) {
+    __shared__ float sh[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, ch0 = blockIdx.y * 64 + 4 * (lane & 15);
+    const int cells = tokens_per_frame - n_prefix;
+    const int R = group * cells;
+    const int p = 4 * wave + (lane >> 4);
+    const long long frame0 = (long long)g * group;
+
+    auto src = [&](int r) {
+        const int f = r / cells, t = r - f * cells;
+        return reinterpret_cast<const float4 *>(tokens + ((frame0 + f) * tokens_per_frame + n_prefix + t) * SSLAM_C + ch0);
+    };
+
+    float4 mean, var;
+    if (train) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = p; r < R; r += 16) {
+            const float4 x = *src(r);
+            s.x = s.x + x.x; s.y = s.y + x.y; s.z = s.z + x.z; s.w = s.w + x.w;
+        }
+        const float4 tot = comb16(s, sh, wave, lane);
+        const float fr = (float)R;
+        mean = make_float4(tot.x / fr, tot.y / fr, tot.z / fr, tot.w / fr);
+        s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = p; r < R; r += 16) {
+            const float4 x = *src(r);
+            const float dx = x.x - mean.x, dy = x.y - mean.y, dz = x.z - mean.z, dw = x.w - mean.w;
+            s.x = __builtin_fmaf(dx, dx, s.x); s.y = __builtin_fmaf(dy, dy, s.y);
+            s.z = __builtin_fmaf(dz, dz, s.z); s.w = __builtin_fmaf(dw, dw, s.w);
+        }
+        const float4 tot2 = comb16(s, sh, wave, lane);
+        var = make_float4(tot2.x / fr, tot2.y / fr, tot2.z / fr, tot2.w / fr);
+        if (tid < 16) {
+            if (out_mean) *reinterpret_cast<float4 *>(out_mean + (long long)g * SSLAM_C + ch0) = mean;
+            if (out_var) *reinterpret_cast<float4 *>(out_var + (long long)g * SSLAM_C + ch0) = var;
+        }
+    } else {
+        mean = *reinterpret_cast<const float4 *>(run_mean + ch0);
+        var = *reinterpret_cast<const float4 *>(run_var + ch0);
+    }
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + ch0);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + ch0);
+    float4 al, bs;
+    al.x = (1.0f / sqrtf(var.x + eps)) * ga.x; al.y = (1.0f / sqrtf(var.y + eps)) * ga.y;
+    al.z = (1.0f / sqrtf(var.z + eps)) * ga.z; al.w = (1.0f / sqrtf(var.w + eps)) * ga.w;
+    bs.x = be.x - mean.x * al.x; bs.y = be.y - mean.y * al.y;
+    bs.z = be.z - mean.z * al.z; bs.w = be.w - mean.w * al.w;
+    for (int r = p; r < R; r += 16) {
+        const float4 x = *src(r);
+        float4 y;
+        y.x = x.x * al.x + bs.x; y.y = x.y * al.y + bs.y; y.z = x.z * al.z + bs.z; y.w = x.w * al.w + bs.w;
+        *reinterpret_cast<float4 *>(out_feat + (frame0 * cells + r) * SSLAM_C + ch0) = y;
+    }
+}
+
+}  // namespace
+
+extern "C" int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                               const float *gamma, const float *beta, const float *run_mean, const float *run_var,
+                               int train, float eps, float *out_feat, float *out_mean, float *out_var, void *stream) {
+    if (!tokens || !gamma || !beta || !out_feat || n_frames <= 0 || group <= 0 || n_prefix < 0 ||
+        tokens_per_frame <= n_prefix)
+        return SSLAM_E_INVALID;
+    if (!train && (!run_mean || !run_var)) return SSLAM_E_INVALID;
+    if (n_frames % group) return SSLAM_E_INVALID;
+    if (((uintptr_t)tokens | (uintptr_t)out_feat | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)run_mean |
+         (uintptr_t)run_var | (uintptr_t)out_mean | (uintptr_t)out_var) & 15)
+        return SSLAM_E_INVALID;
+    if ((long long)group * (tokens_per_frame - n_prefix) > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_tokens_kernel, dim3(n_frames / group, SSLAM_C / 64), dim3(256), 0, (hipStream_t)stream, tokens,
+                       tokens_per_frame, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out_feat,
+                       out_mean, out_var);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}

@@ -1,0 +1,228 @@
+// match.hip - M1..M5 core: cosine-similarity GEMM fused with row / column arg-max, then the mutual check,
+// thresholds, quality score and ordered compaction of M1.
+// Replaces torch.mm + argmax(dim=1) + argmax(dim=0) + mutual/threshold/quality code of
+// SequenceMatcher.match_with_quality (reference semantic-slam/visualize_matches_sequence.py:138-197) and the sibling
+// matchers (visualize_matches.py:105-109, train.py:423-425, test/test_descriptor_quality.py:116-123,
+// test/test_tracking.py:159-160).
+//
+// sim_argmax: grid (query blocks of 128, direction, pair).  Direction 0 finds for every row of d1 its best row of
+// d2 (nn12), direction 1 swaps the roles (nn21): S[i][j] and S^T[j][i] are the same fma chain (a*b commutes), so
+// both directions see bit-identical similarities and the K x K matrix is never written to memory.
+// The MFMA tile is oriented with the QUERY on the lane (B operand) and the candidates on the accumulator rows
+// (A operand): each lane then owns one query and scans its 16 candidate rows per tile in increasing index with a
+// strict '>' - a register-local arg-max that keeps the first maximum (torch / numpy semantics); only
+// the two half-waves and the two candidate waves are merged at the end (value, then lower index).
+// Roofline: MFMA-bound (2 * n1 * n2 * 128 * 2 FLOP per pair incl. both directions; 128 MFLOP at 500 keypoints).
+#include "common.h"
+
+namespace {
+
+constexpr int QB = 128;            // queries per workgroup
+constexpr int CB = 64;             // candidates per stage
+constexpr int LDD = SSLAM_D + 4;   // 132-float rows: 528 B = 33 x 16 B -> conflict-free b128 fragment reads
+
+__device__ __forceinline__ void stage_rows(float *dst, const float *__restrict__ src, int first, int n_valid, int rows,
+                                           int tid) {
+    // rows x 128 floats -> KP8 image; rows beyond n_valid are zero (they are masked out of the arg-max anyway)
+    for (int it = tid; it < rows * 16; it += 512) {
+        const int row = it >> 4, g = it & 15;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (first + row < n_valid) {
+            const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(first + row) * SSLAM_D + 8 * g);
+            lo = p[0];
+            hi = p[1];
+        }
+        float4 ev, od;
+        kp8_split(lo, hi, ev, od);
+        *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g) = ev;
+        *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g + 4) = od;
+    }
+}
+
+__global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
+                                                          const float *__restrict__ desc2, long long stride2, int n2,
+                                                          int *__restrict__ nn12, float *__restrict__ s12,
+                                                          int *__restrict__ nn21, float *__restrict__ s21,
+                                                          float *__restrict__ second12) {
+    __shared__ __attribute__((aligned(16))) float smem[(QB + 2 * CB) * LDD];
+    float *Qs = smem, *Cs = smem + QB * LDD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wq = wave & 3, wc = wave >> 2;
+    const int dir = blockIdx.y;
+    const long long pair = blockIdx.z;
+    const float *q = dir == 0 ? desc1 + pair * stride1 : desc2 + pair * stride2;
+    const float *c = dir == 0 ? desc2 + pair * stride2 : desc1 + pair * stride1;
+    const int nq = dir == 0 ? n1 : n2, nc = dir == 0 ? n2 : n1;
+    const int q0 = blockIdx.x * QB;
+    if (q0 >= nq) return;
+    int *o_idx = (dir == 0 ? nn12 + pair * n1 : nn21 + pair * n2);
+    float *o_val = dir == 0 ? (s12 ? s12 + pair * n1 : nullptr) : (s21 ? s21 + pair * n2 : nullptr);
+    float *o_sec = (dir == 0 && second12) ? second12 + pair * n1 : nullptr;
+
+    stage_rows(Qs, q, q0, nq, QB, tid);
+    stage_rows(Cs, c, 0, nc, CB, tid);
+    __syncthreads();
+
+    float best = -INFINITY, second = -INFINITY;   // second: best of the row once the winner is removed
+    int besti = 0x7fffffff;
+    const int nstage = (nc + CB - 1) / CB;
+    const float *B = Qs + (wq * 32 + r) * LDD + 4 * h;
+    for (int s = 0; s < nstage; s++) {
+        if (s + 1 < nstage) stage_rows(Cs + ((s + 1) & 1) * CB * LDD, c, (s + 1) * CB, nc, CB, tid);
+        const float *A = Cs + (s & 1) * CB * LDD + (wc * 32 + r) * LDD + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < SSLAM_D / 8; g++) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(B + 8 * g);
+#pragma unroll
+            for (int st = 0; st < 4; st++) acc = mfma32(a[st], b[st], acc);
+        }
+        const int jbase = s * CB + wc * 32;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int j = jbase + crow(e, h);
+            if (j < nc) {
+                const float v = acc[e];
+                if (v > best) {
+                    second = best;
+                    best = v;
+                    besti = j;
+                } else if (v > second) {
+                    second = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // merge the two half-waves (same query, interleaved candidate rows), then the two candidate waves
+    {
+        const float ov = __shfl_xor(best, 32), os = __shfl_xor(second, 32);
+        const int oi = __shfl_xor(besti, 32);
+        if (ov > best || (ov == best && oi < besti)) {
+            second = fmaxf(best, os);     // the loser's best competes with the winner's runner-up
+            best = ov;
+            besti = oi;
+        } else {
+            second = fmaxf(second, ov);
+        }
+    }
+    float *mv = smem;                                     // [2][128]
+    int *mi = reinterpret_cast<int *>(smem + 2 * QB);      // [2][128]
+    float *ms = smem + 4 * QB;                             // [2][128]
+    if (h == 0) {
+        mv[wc * QB + wq * 32 + r] = best;
+        mi[wc * QB + wq * 32 + r] = besti;
+        ms[wc * QB + wq * 32 + r] = second;
+    }
+    __syncthreads();
+    if (tid < QB && q0 + tid < nq) {
+        float v = mv[tid], sc = ms[tid];
+        int i = mi[tid];
+        const float v1 = mv[QB + tid], sc1 = ms[QB + tid];
+        const int i1 = mi[QB + tid];
+        if (v1 > v || (v1 == v && i1 < i)) {
+            sc = fmaxf(v, sc1);
+            v = v1;
+            i = i1;
+        } else {
+            sc = fmaxf(sc, v1);
+        }
+        o_idx[q0 + tid] = i;
+        if (o_val) o_val[q0 + tid] = v;
+        if (o_sec) o_sec[q0 + tid] = sc;
+    }
+}
+
+// one workgroup per pair: mutual check, thresholds, quality, ordered compaction (ascending idx1)
+__global__ __launch_bounds__(256) void match_finalize_kernel(const int *__restrict__ nn12, const float *__restrict__ s12,
+                                                              const int *__restrict__ nn21, int n1, int n2,
+                                                              const float *__restrict__ sc1, long long ss1,
+                                                              const float *__restrict__ sc2, long long ss2,
+                                                              const float *__restrict__ in1, const float *__restrict__ in2,
+                                                              float w_desc, float w_sal, float t_sal, float t_sim,
+                                                              float t_int, long long *__restrict__ matches,
+                                                              float *__restrict__ quality, int *__restrict__ count) {
+    __shared__ int wave_tot[4];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p = blockIdx.x;
+    nn12 += p * n1;
+    s12 += p * n1;
+    nn21 += p * n2;
+    sc1 += p * ss1;
+    sc2 += p * ss2;
+    if (in1) in1 += p * ss1;
+    if (in2) in2 += p * ss2;
+    matches += p * n1 * 2;
+    quality += p * n1;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < n1; base += 256) {
+        const int i = base + tid;
+        bool ok = false;
+        int j = 0;
+        float sim = 0.f, avg = 0.f;
+        if (i < n1) {
+            j = nn12[i];
+            if (nn21[j] == i) {                                               // :149
+                sim = s12[i];
+                avg = (sc1[i] + sc2[j]) / 2.0f;                               // :163
+                ok = (avg >= t_sal) && (sim >= t_sim);                        // :166-168
+                if (in1 && in2) ok = ok && ((in1[i] + in2[j]) / 2.0f >= t_int);   // :171-176
+            }
+        }
+        int inc = ok ? 1 : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        int off0 = running;
+        for (int w = 0; w < wave; w++) off0 += wave_tot[w];
+        if (ok) {
+            const int slot = off0 + inc - 1;
+            matches[2 * slot] = i;
+            matches[2 * slot + 1] = j;
+            quality[slot] = w_desc * sim + w_sal * avg;                       // :189-192
+        }
+        __syncthreads();
+        if (tid == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[p] = running;
+}
+
+}  // namespace
+
+extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2,
+                                int n2, int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12,
+                                void *stream) {
+    if (!desc1 || !desc2 || !nn12 || !nn21 || n1 <= 0 || n2 <= 0 || n_pairs <= 0) return SSLAM_E_INVALID;
+    if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15 || (stride1 & 3) || (stride2 & 3)) return SSLAM_E_INVALID;
+    if (n_pairs > 65535) return SSLAM_E_UNSUPPORTED;
+    const int nmax = n1 > n2 ? n1 : n2;
+    hipLaunchKernelGGL(sim_argmax_kernel, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(512), 0, (hipStream_t)stream, desc1,
+                       stride1, n1, desc2, stride2, n2, nn12, s12, nn21, s21, second12);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_match_finalize(const int32_t *nn12, const float *s12, const int32_t *nn21, int n1, int n2, int n_pairs,
+                                    const float *scores1, long long sstride1, const float *scores2, long long sstride2,
+                                    const float *intensity1, const float *intensity2, float w_desc, float w_sal,
+                                    float min_saliency, float min_sim, float min_intensity, int64_t *matches,
+                                    float *quality, int32_t *count, void *stream) {
+    if (!nn12 || !s12 || !nn21 || !scores1 || !scores2 || !matches || !quality || !count || n1 <= 0 || n2 <= 0 ||
+        n_pairs <= 0)
+        return SSLAM_E_INVALID;
+    hipLaunchKernelGGL(match_finalize_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, nn12, s12, nn21, n1, n2,
+                       scores1, sstride1, scores2, sstride2, intensity1, intensity2, w_desc, w_sal, min_saliency, min_sim,
+                       min_intensity, (long long *)matches, quality, count);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}

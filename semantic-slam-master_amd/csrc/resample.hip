@@ -1,0 +1,193 @@
+// resample.hip - A0 (image preprocessing) and A9 (per-keypoint intensity): Pillow's antialiased resampling in its
+// 22-bit fixed-point integer arithmetic, bit-exact.
+// Replaces transforms.Compose([Resize, ToTensor, Normalize]) applied at reference
+// semantic-slam/visualize_matches_sequence.py:59-67,72 and the intensity lookup at :87-95.
+// The arithmetic is third-party (Pillow's libImaging/Resample.c, unpinned in the reference's requirements.txt:5);
+// it is restated from the published algorithm and pinned by golden vectors made with Pillow 12.2.0.
+//
+// Byte / integer work, HBM-bound: 921 600 B in and 2 408 448 B out per 640x480 -> 448x448 frame (A0); A9 touches
+// at most ksize_v * ksize_h source pixels per keypoint and never materialises the resized image.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int PREC = 22;   // Pillow PRECISION_BITS = 32 - 8 - 2
+constexpr int TX = 64, TY = 16, MAXR = 64;
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= PREC;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
+                                                          const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
+                                                          const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
+                                                          float *__restrict__ out) {
+    __shared__ uint8_t tmp[MAXR][TX][3];
+    __shared__ float lut[3][256];
+    const int tid = threadIdx.x;
+    const long long f = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int ty1 = min(y0 + TY, size) - 1;
+    const int rmin = bv[2 * y0], rmax = bv[2 * ty1] + bv[2 * ty1 + 1];   // input rows [rmin, rmax)
+    const int nrows = rmax - rmin;
+    const uint8_t *src = img + f * h * w * 3;
+    {   // ToTensor (/255) and Normalize ((x - mean) / std) as a 256-entry table per channel, in fp32
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; c++) lut[c][tid] = ((float)tid / 255.0f - mean[c]) / sd[c];
+    }
+    // horizontal pass into LDS (uint8, as Pillow's intermediate image)
+    for (int it = tid; it < nrows * TX; it += 256) {
+        const int rr = it / TX, xx = it % TX;
+        const int ox = x0 + xx;
+        if (ox < size) {
+            const int xmin = bh[2 * ox], xn = bh[2 * ox + 1];
+            const int *k = ch + (long long)ox * ksh;
+            const uint8_t *p = src + ((long long)(rmin + rr) * w + xmin) * 3;
+            int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+            for (int t = 0; t < xn; t++) {
+                const int kk = k[t];
+                s0 += p[3 * t] * kk;
+                s1 += p[3 * t + 1] * kk;
+                s2 += p[3 * t + 2] * kk;
+            }
+            tmp[rr][xx][0] = (uint8_t)clip8(s0);
+            tmp[rr][xx][1] = (uint8_t)clip8(s1);
+            tmp[rr][xx][2] = (uint8_t)clip8(s2);
+        }
+    }
+    __syncthreads();
+    // vertical pass + normalisation, planar fp32 output
+    const long long plane = (long long)size * size;
+    for (int it = tid; it < TY * TX * 3; it += 256) {
+        const int c = it / (TY * TX), rem = it % (TY * TX), yy = rem / TX, xx = rem % TX;
+        const int oy = y0 + yy, ox = x0 + xx;
+        if (oy < size && ox < size) {
+            const int ymin = bv[2 * oy] - rmin, yn = bv[2 * oy + 1];
+            const int *k = cv + (long long)oy * ksv;
+            int s = 1 << (PREC - 1);
+            for (int t = 0; t < yn; t++) s += tmp[ymin + t][xx][c] * k[t];
+            out[(f * 3 + c) * plane + (long long)oy * size + ox] = lut[c][clip8(s)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void intensity_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
+                                                         const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
+                                                         const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
+                                                         const float *__restrict__ kp_pixel, int K, long long total,
+                                                         float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long f = i / K;
+    const uint8_t *src = img + f * h * w * 3;
+    // numpy round() is half-to-even; clip to the resized image (visualize_matches_sequence.py:93-94)
+    int X = (int)__builtin_rintf(kp_pixel[2 * i]), Y = (int)__builtin_rintf(kp_pixel[2 * i + 1]);
+    X = min(max(X, 0), size - 1);
+    Y = min(max(Y, 0), size - 1);
+    const int xmin = bh[2 * X], xn = bh[2 * X + 1], ymin = bv[2 * Y], yn = bv[2 * Y + 1];
+    const int *kh = ch + (long long)X * ksh, *kv = cv + (long long)Y * ksv;
+    int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
+    for (int ry = 0; ry < yn; ry++) {
+        const uint8_t *p = src + ((long long)(ymin + ry) * w + xmin) * 3;
+        int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+        for (int t = 0; t < xn; t++) {
+            const int kk = kh[t];
+            s0 += p[3 * t] * kk;
+            s1 += p[3 * t + 1] * kk;
+            s2 += p[3 * t + 2] * kk;
+        }
+        const int kk = kv[ry];
+        a0 += clip8(s0) * kk;
+        a1 += clip8(s1) * kk;
+        a2 += clip8(s2) * kk;
+    }
+    const int R = clip8(a0), Gc = clip8(a1), B = clip8(a2);
+    const int L = (R * 19595 + Gc * 38470 + B * 7471 + 0x8000) >> 16;   // Pillow "L" (ITU-R 601-2, 16-bit fixed)
+    out[i] = (float)L / 255.0f;
+}
+
+double filt_bilinear(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+double filt_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+}  // namespace
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for one axis (host, double precision, same operation order)
+extern "C" int sslam_resample_table_host(int in_size, int out_size, int filter, int32_t *bounds, int32_t *coefs,
+                                         int coefs_capacity) {
+    if (in_size <= 0 || out_size <= 0 || !bounds || !coefs || filter < 0 || filter > 1) return SSLAM_E_INVALID;
+    double (*fn)(double) = filter ? filt_bicubic : filt_bilinear;
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = (filter ? 2.0 : 1.0) * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    if (ksize > SSLAM_MAX_TAPS) return SSLAM_E_UNSUPPORTED;
+    if ((long long)ksize * out_size > coefs_capacity) return SSLAM_E_INVALID;
+    double k[SSLAM_MAX_TAPS];
+    for (int xx = 0; xx < out_size; xx++) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        const double ss = 1.0 / filterscale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        int x;
+        for (x = 0; x < xmax; x++) {
+            const double wgt = fn((x + xmin - center + 0.5) * ss);
+            k[x] = wgt;
+            ww += wgt;
+        }
+        for (x = 0; x < xmax; x++)
+            if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; x++) k[x] = 0;
+        for (x = 0; x < ksize; x++)
+            coefs[(long long)xx * ksize + x] =
+                k[x] < 0 ? (int32_t)(-0.5 + k[x] * (1 << PREC)) : (int32_t)(0.5 + k[x] * (1 << PREC));
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    return ksize;
+}
+
+extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                                   const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                                   int ksize_v, float *out_chw, void *stream) {
+    if (!img || !bounds_h || !coefs_h || !bounds_v || !coefs_v || !out_chw || n <= 0 || h <= 0 || w <= 0 || size <= 0)
+        return SSLAM_E_INVALID;
+    if (ksize_h <= 0 || ksize_v <= 0 || ksize_h > SSLAM_MAX_TAPS || ksize_v > SSLAM_MAX_TAPS) return SSLAM_E_INVALID;
+    // input rows one output tile can need: TY output rows span TY*scale input rows plus the filter support
+    if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
+    if (n > 65535) return SSLAM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((size + TX - 1) / TX, (size + TY - 1) / TY, n), dim3(256), 0,
+                       (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                                        const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                                        int ksize_v, const float *kp_pixel, int K, float *out, void *stream) {
+    if (!img || !bounds_h || !coefs_h || !bounds_v || !coefs_v || !kp_pixel || !out || n <= 0 || h <= 0 || w <= 0 ||
+        size <= 0 || K <= 0)
+        return SSLAM_E_INVALID;
+    const long long total = (long long)n * K;
+    hipLaunchKernelGGL(intensity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, h, w,
+                       size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, kp_pixel, K, total, out);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}

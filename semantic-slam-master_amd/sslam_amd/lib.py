@@ -1,0 +1,253 @@
+"""ctypes binding of libsslam_hip.so (include/sslam_hip.h) for torch tensors.
+
+PyTorch is used for device memory and streams only: every wrapper passes raw device pointers and the current
+HIP stream to the C ABI.  There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(_PKG, "csrc")
+SO_PATH = os.path.join(CSRC, "libsslam_hip.so")
+
+OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
+_ERR = {E_INVALID: "invalid argument", E_UNSUPPORTED: "unsupported shape", E_LAUNCH: "kernel launch failed"}
+
+C_FEAT, HID, D_OUT = 384, 384, 128
+MAX_TAPS = 32
+
+
+class SslamHipError(RuntimeError):
+    pass
+
+
+class RefinerLayout(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("total", C.c_longlong), ("in_w", C.c_longlong), ("in_b", C.c_longlong),
+                ("blk", (C.c_longlong * 8) * 8), ("out_w", C.c_longlong), ("out_b", C.c_longlong)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "sslam_hip.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return SO_PATH
+
+
+_lib = None
+
+EXPORTS = [
+    "sslam_version", "sslam_arch", "sslam_launch_count", "sslam_pack_conv3x3_host", "sslam_pack_linear_host",
+    "sslam_resample_table_host", "sslam_preprocess_u8", "sslam_bn_tokens", "sslam_selector_saliency",
+    "sslam_select_keypoints", "sslam_gather", "sslam_refiner_layout", "sslam_refiner_pack_host", "sslam_refine",
+    "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
+]
+
+
+def lib():
+    """Load libsslam_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise SslamHipError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                f"(or `make -C {CSRC}`); this package has no non-HIP execution path")
+        L = C.CDLL(SO_PATH)
+        L.sslam_arch.restype = C.c_char_p
+        L.sslam_launch_count.restype = C.c_longlong
+        p, i, ll, f, d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
+        L.sslam_pack_conv3x3_host.argtypes = [p, i, p]
+        L.sslam_pack_linear_host.argtypes = [p, i, i, p]
+        L.sslam_resample_table_host.argtypes = [i, i, i, p, p, i]
+        L.sslam_preprocess_u8.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, p]
+        L.sslam_bn_tokens.argtypes = [p, i, i, i, i, p, p, p, p, i, f, p, p, p, p]
+        L.sslam_selector_saliency.argtypes = [p, i, i, p, p, p, p, i, p, p]
+        L.sslam_select_keypoints.argtypes = [p, i, i, i, i, d, p, p, p, p, p, p]
+        L.sslam_gather.argtypes = [p, i, i, p, i, p, p]
+        L.sslam_refiner_layout.argtypes = [i, C.POINTER(RefinerLayout)]
+        L.sslam_refiner_pack_host.argtypes = [p, i, p]
+        L.sslam_refine.argtypes = [p, ll, p, i, p, p]
+        L.sslam_gather_refine.argtypes = [p, i, i, p, i, p, i, p, p]
+        L.sslam_keypoint_intensity.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, i, p, p]
+        L.sslam_sim_argmax.argtypes = [p, ll, i, p, ll, i, i, p, p, p, p, p, p]
+        L.sslam_match_finalize.argtypes = [p, p, p, i, i, i, p, ll, p, ll, p, p, f, f, f, f, f, p, p, p, p]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != OK:
+        if rc == E_INVALID:
+            raise ValueError(f"{what}: {_ERR[rc]}")
+        raise SslamHipError(f"{what}: {_ERR.get(rc, rc)}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def launch_count() -> int:
+    return int(lib().sslam_launch_count())
+
+
+# ------------------------------------------------------------------------------------------ host-side packing
+def pack_conv3x3(w: np.ndarray) -> np.ndarray:
+    w = np.ascontiguousarray(w, np.float32)
+    hs = w.shape[0]
+    assert w.shape == (hs, C_FEAT, 3, 3)
+    out = np.empty(9 * C_FEAT * hs, np.float32)
+    _check(lib().sslam_pack_conv3x3_host(w.ctypes.data, hs, out.ctypes.data), "pack_conv3x3")
+    return out
+
+
+def refiner_layout(n_blocks: int) -> RefinerLayout:
+    lay = RefinerLayout()
+    _check(lib().sslam_refiner_layout(n_blocks, C.byref(lay)), "refiner_layout")
+    return lay
+
+
+def pack_refiner(weights: list, n_blocks: int) -> np.ndarray:
+    """weights: 4 + 8*n_blocks fp32 arrays in state_dict order (input_proj, blocks, output_proj)."""
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    assert len(ws) == 4 + 8 * n_blocks
+    lay = refiner_layout(n_blocks)
+    out = np.empty(lay.total, np.float32)
+    arr = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    _check(lib().sslam_refiner_pack_host(arr, n_blocks, out.ctypes.data), "refiner_pack")
+    return out
+
+
+def resample_table(in_size: int, out_size: int, bicubic: bool):
+    bounds = np.empty(out_size * 2, np.int32)
+    coefs = np.empty(out_size * MAX_TAPS, np.int32)
+    ks = lib().sslam_resample_table_host(in_size, out_size, int(bicubic), bounds.ctypes.data, coefs.ctypes.data, coefs.size)
+    if ks < 0:
+        _check(ks, "resample_table")
+    return bounds, coefs[: out_size * ks].copy(), ks
+
+
+# ------------------------------------------------------------------------------------------------ device calls
+def preprocess_u8(img, size, tab_h, tab_v, out=None):
+    n, h, w, _ = img.shape
+    assert img.dtype == torch.uint8
+    if out is None:
+        out = torch.empty((n, 3, size, size), dtype=torch.float32, device=img.device)
+    (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
+    _check(lib().sslam_preprocess_u8(_dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(out), _stream()),
+           "preprocess_u8")
+    return out
+
+
+def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out=None, want_stats=True):
+    n, t, c = tokens.shape
+    assert c == C_FEAT and tokens.dtype == torch.float32
+    cells = t - n_prefix
+    if out is None:
+        out = torch.empty((n, cells, c), dtype=torch.float32, device=tokens.device)
+    mean = var = None
+    if train and want_stats:
+        mean = torch.empty((n // group, c), dtype=torch.float32, device=tokens.device)
+        var = torch.empty_like(mean)
+    _check(lib().sslam_bn_tokens(_dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean), _dp(run_var),
+                                 int(bool(train)), C.c_float(eps), _dp(out), _dp(mean), _dp(var), _stream()), "bn_tokens")
+    return out, mean, var
+
+
+def selector_saliency(feat, w1p, b1, w2, b2, hs, out=None):
+    n, g = feat.shape[0], feat.shape[1]
+    if out is None:
+        out = torch.empty((n, g, g), dtype=torch.float32, device=feat.device)
+    _check(lib().sslam_selector_saliency(_dp(feat), n, g, _dp(w1p), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out), _stream()),
+           "selector_saliency")
+    return out
+
+
+def select_keypoints(sal, K, radius=2, pct=0.5, want_idx=True, want_pixel=True):
+    n, g = sal.shape[0], sal.shape[1]
+    dev = sal.device
+    kp = torch.empty((n, K, 2), dtype=torch.float32, device=dev)
+    sc = torch.empty((n, K), dtype=torch.float32, device=dev)
+    idx = torch.empty((n, K), dtype=torch.int32, device=dev) if want_idx else None
+    px = torch.empty((n, K, 2), dtype=torch.float32, device=dev) if want_pixel else None
+    st = torch.empty((n,), dtype=torch.int32, device=dev)
+    _check(lib().sslam_select_keypoints(_dp(sal), n, g, K, radius, C.c_double(pct), _dp(kp), _dp(sc), _dp(idx), _dp(px),
+                                        _dp(st), _stream()), "select_keypoints")
+    return kp, sc, idx, px, st
+
+
+def gather(feat, kp, out=None):
+    n, g = feat.shape[0], feat.shape[1]
+    K = kp.shape[1]
+    if out is None:
+        out = torch.empty((n, K, C_FEAT), dtype=torch.float32, device=feat.device)
+    _check(lib().sslam_gather(_dp(feat), n, g, _dp(kp), K, _dp(out), _stream()), "gather")
+    return out
+
+
+def refine(x, packed, n_blocks, out=None):
+    rows = x.numel() // C_FEAT
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (D_OUT,), dtype=torch.float32, device=x.device)
+    _check(lib().sslam_refine(_dp(x), rows, _dp(packed), n_blocks, _dp(out), _stream()), "refine")
+    return out
+
+
+def gather_refine(feat, kp, packed, n_blocks, out=None):
+    n, g = feat.shape[0], feat.shape[1]
+    K = kp.shape[1]
+    if out is None:
+        out = torch.empty((n, K, D_OUT), dtype=torch.float32, device=feat.device)
+    _check(lib().sslam_gather_refine(_dp(feat), n, g, _dp(kp), K, _dp(packed), n_blocks, _dp(out), _stream()), "gather_refine")
+    return out
+
+
+def keypoint_intensity(img, size, tab_h, tab_v, kp_pixel, out=None):
+    n, h, w, _ = img.shape
+    K = kp_pixel.shape[1]
+    if out is None:
+        out = torch.empty((n, K), dtype=torch.float32, device=img.device)
+    (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
+    _check(lib().sslam_keypoint_intensity(_dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(kp_pixel), K,
+                                          _dp(out), _stream()), "keypoint_intensity")
+    return out
+
+
+def sim_argmax(d1, stride1, n1, d2, stride2, n2, n_pairs, want_s21=False, want_second=False):
+    dev = d1.device
+    nn12 = torch.empty((n_pairs, n1), dtype=torch.int32, device=dev)
+    s12 = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
+    nn21 = torch.empty((n_pairs, n2), dtype=torch.int32, device=dev)
+    s21 = torch.empty((n_pairs, n2), dtype=torch.float32, device=dev) if want_s21 else None
+    sec = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev) if want_second else None
+    _check(lib().sslam_sim_argmax(C.c_void_p(d1.data_ptr()), stride1, n1, C.c_void_p(d2.data_ptr()), stride2, n2, n_pairs,
+                                  _dp(nn12), _dp(s12), _dp(nn21), _dp(s21), _dp(sec), _stream()), "sim_argmax")
+    return nn12, s12, nn21, s21, sec
+
+
+def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in2, w_desc, w_sal, t_sal, t_sim, t_int):
+    dev = nn12.device
+    matches = torch.empty((n_pairs, n1, 2), dtype=torch.int64, device=dev)
+    quality = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
+    count = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    f = C.c_float
+    _check(lib().sslam_match_finalize(_dp(nn12), _dp(s12), _dp(nn21), n1, n2, n_pairs, C.c_void_p(sc1.data_ptr()), ss1,
+                                      C.c_void_p(sc2.data_ptr()), ss2,
+                                      None if in1 is None else C.c_void_p(in1.data_ptr()),
+                                      None if in2 is None else C.c_void_p(in2.data_ptr()),
+                                      f(w_desc), f(w_sal), f(t_sal), f(t_sim), f(t_int), _dp(matches), _dp(quality),
+                                      _dp(count), _stream()), "match_finalize")
+    return matches, quality, count

@@ -1,0 +1,190 @@
+"""Batched extraction + matching pipeline on one MI355X: the streaming counterpart of the reference's per-pair
+harness (SequenceMatcher.extract + process_spacing, semantic-slam/visualize_matches_sequence.py:69-104, 272-357).
+
+Differences from the reference harness, by design: every frame is extracted ONCE and its
+descriptors reused for all pairs (as test/test_tracking.py:176-177 does); a whole chunk of frames goes through each
+fused HIP stage in one launch; BatchNorm statistics stay per frame so results equal the reference's
+B = 1 calls; nothing synchronises with the host until the caller reads the outputs.
+
+PyTorch is plumbing only (device buffers, streams); all arithmetic runs in libsslam_hip.so via sslam_amd.lib.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import lib
+
+PATCH = 16
+N_PREFIX = 5   # CLS + 4 register tokens, dino_backbone.py:51,91
+
+
+@dataclass
+class ExtractorConfig:
+    """Shapes and thresholds; defaults = semantic-slam/configs/train_config.yaml:5-17 and the CLI defaults of
+    visualize_matches_sequence.py:381-388."""
+    input_size: int = 448
+    num_keypoints: int = 500
+    nms_radius: int = 2
+    min_score_percentile: float = 0.50
+    bn_train_mode: bool = True          # visualize_* scripts never call backbone.eval()
+    bn_eps: float = 1e-5
+    saliency_weight: float = 0.3
+    min_saliency: float = 0.5
+    min_descriptor_sim: float = 0.7
+    min_intensity: float = 0.15
+    use_intensity: bool = True
+    spacing: int = 1
+    chunk_frames: int = 1024            # frames per launch group; 1024 x 28^2 x 384 fp32 = 1.2 GB of features
+
+    @property
+    def grid(self) -> int:
+        return self.input_size // PATCH
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+REFINER_ORDER_HEAD = ["input_proj.weight", "input_proj.bias"]
+REFINER_ORDER_BLOCK = ["norm1.weight", "norm1.bias", "fc1.weight", "fc1.bias", "norm2.weight", "norm2.bias",
+                       "fc2.weight", "fc2.bias"]
+REFINER_ORDER_TAIL = ["output_proj.weight", "output_proj.bias"]
+
+
+def refiner_weight_list(sd: dict):
+    n_blocks = len({k.split(".")[1] for k in sd if k.startswith("residual_blocks.")})
+    keys = list(REFINER_ORDER_HEAD)
+    for i in range(n_blocks):
+        keys += [f"residual_blocks.{i}.{k}" for k in REFINER_ORDER_BLOCK]
+    keys += REFINER_ORDER_TAIL
+    return [np.ascontiguousarray(_np(sd[k]), np.float32) for k in keys], n_blocks
+
+
+class PackedSelector:
+    """Device-resident, kernel-order copy of a KeypointSelector state_dict."""
+
+    def __init__(self, sd: dict, device):
+        w1 = np.ascontiguousarray(_np(sd["conv.0.weight"]), np.float32)
+        self.hidden = int(w1.shape[0])
+        if self.hidden not in (128, 256) or w1.shape[1:] != (lib.C_FEAT, 3, 3):
+            raise lib.SslamHipError(f"selector shape {w1.shape} unsupported by the HIP kernels (hidden 128/256, C 384)")
+        self.w1p = torch.from_numpy(lib.pack_conv3x3(w1)).to(device)
+        self.b1 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.0.bias"]), np.float32)).to(device)
+        self.w2 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.2.weight"]), np.float32).reshape(-1)).to(device)
+        self.b2 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.2.bias"]), np.float32).reshape(-1)).to(device)
+
+
+class PackedRefiner:
+    """Device-resident packed DescriptorRefiner weights (one buffer, sslam_refiner_layout order)."""
+
+    def __init__(self, sd: dict, device):
+        ws, self.n_blocks = refiner_weight_list(sd)
+        if ws[0].shape != (lib.HID, lib.C_FEAT) or ws[-2].shape != (lib.D_OUT, lib.HID):
+            raise lib.SslamHipError("refiner shape unsupported by the HIP kernels (384 -> 384 -> 128)")
+        self.packed = torch.from_numpy(lib.pack_refiner(ws, self.n_blocks)).to(device)
+
+
+class ResampleTables:
+    """Pillow coefficient tables on the device, cached per (height, width, size, filter)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._cache = {}
+
+    def get(self, h: int, w: int, size: int, bicubic: bool):
+        key = (h, w, size, bicubic)
+        if key not in self._cache:
+            tabs = []
+            for n_in in (w, h):
+                b, c, k = lib.resample_table(n_in, size, bicubic)
+                tabs.append((torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), k))
+            self._cache[key] = tuple(tabs)
+        return self._cache[key]
+
+
+class SequencePipeline:
+    def __init__(self, cfg: ExtractorConfig, selector_state: dict, refiner_state: dict, bn_state: dict | None = None,
+                 device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        lib.lib()   # fail loudly if the HIP library is not built
+        self.selector = PackedSelector(selector_state, self.device)
+        self.refiner = PackedRefiner(refiner_state, self.device)
+        c = lib.C_FEAT
+        bn = bn_state or {}
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.bn_gamma = torch.as_tensor(_np(bn.get("weight", np.ones(c))), **f32).contiguous()
+        self.bn_beta = torch.as_tensor(_np(bn.get("bias", np.zeros(c))), **f32).contiguous()
+        self.bn_mean = torch.as_tensor(_np(bn.get("running_mean", np.zeros(c))), **f32).contiguous()
+        self.bn_var = torch.as_tensor(_np(bn.get("running_var", np.ones(c))), **f32).contiguous()
+        self.tables = ResampleTables(self.device)
+
+    # ---------------------------------------------------------------------------------------------- stages
+    def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """A0: (N, H, W, 3) uint8 -> (N, 3, S, S) fp32, Pillow-exact (the ViT input)."""
+        n, h, w, _ = images_u8.shape
+        th, tv = self.tables.get(h, w, self.cfg.input_size, False)
+        return lib.preprocess_u8(images_u8, self.cfg.input_size, th, tv)
+
+    def features(self, tokens: torch.Tensor) -> torch.Tensor:
+        """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features."""
+        g = self.cfg.grid
+        if tokens.shape[1] != N_PREFIX + g * g:
+            raise AssertionError(f"Expected {g * g} patches, got {tokens.shape[1] - N_PREFIX}")   # dino_backbone.py:94
+        feat, _, _ = lib.bn_tokens(tokens, N_PREFIX, 1, self.bn_gamma, self.bn_beta, self.bn_mean, self.bn_var,
+                                   self.cfg.bn_train_mode, self.cfg.bn_eps, want_stats=False)
+        return feat.view(tokens.shape[0], g, g, lib.C_FEAT)
+
+    def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
+        """A2..A9 for a batch of frames.  Returns device tensors; no host synchronisation."""
+        cfg, s = self.cfg, self.selector
+        feat = self.features(tokens)
+        sal = lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden)
+        kp, sc, idx, px, st = lib.select_keypoints(sal, cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile)
+        desc = lib.gather_refine(feat, kp, self.refiner.packed, self.refiner.n_blocks)
+        out = dict(saliency=sal, keypoints_patch=kp, keypoints_pixel=px, scores=sc, idx=idx, descriptors=desc, status=st)
+        if images_u8 is not None:
+            n, h, w, _ = images_u8.shape
+            th, tv = self.tables.get(h, w, cfg.input_size, True)
+            out["intensity"] = lib.keypoint_intensity(images_u8, cfg.input_size, th, tv, px)
+        return out
+
+    def match(self, desc, scores, intensity=None, spacing: int | None = None, halo: dict | None = None) -> dict:
+        """M1 for all pairs (i, i + spacing) inside the batch.  desc (N, K, 128), scores (N, K), intensity (N, K)."""
+        cfg = self.cfg
+        sp = cfg.spacing if spacing is None else spacing
+        n, k = desc.shape[0], desc.shape[1]
+        n_pairs = n - sp
+        if n_pairs <= 0:
+            z = torch.zeros
+            return dict(matches=z((0, k, 2), dtype=torch.int64, device=desc.device),
+                        quality=z((0, k), dtype=torch.float32, device=desc.device),
+                        match_count=z((0,), dtype=torch.int32, device=desc.device))
+        nn12, s12, nn21, _, _ = lib.sim_argmax(desc, k * lib.D_OUT, k, desc[sp:], k * lib.D_OUT, k, n_pairs)
+        use_int = cfg.use_intensity and intensity is not None
+        mt, q, cnt = lib.match_finalize(nn12, s12, nn21, k, k, n_pairs, scores, k, scores[sp:], k,
+                                        intensity if use_int else None, intensity[sp:] if use_int else None,
+                                        1.0 - cfg.saliency_weight, cfg.saliency_weight, cfg.min_saliency,
+                                        cfg.min_descriptor_sim, cfg.min_intensity)
+        return dict(matches=mt, quality=q, match_count=cnt, nn12=nn12, nn21=nn21, sim=s12)
+
+    def run(self, images_u8: torch.Tensor | None, tokens: torch.Tensor, with_preprocess: bool = False) -> dict:
+        """One pass of the hot path over a frame sequence: extract every frame once, match (i, i+spacing)."""
+        cfg = self.cfg
+        n = tokens.shape[0]
+        parts = []
+        vit_in = None
+        for a in range(0, n, cfg.chunk_frames):
+            b = min(a + cfg.chunk_frames, n)
+            img = None if images_u8 is None else images_u8[a:b]
+            if with_preprocess and img is not None:
+                vit_in = self.preprocess(img)      # A0: would feed the ViT (A1, third-party)
+            parts.append(self.extract(tokens[a:b], img))
+        out = {k: (torch.cat([p[k] for p in parts]) if len(parts) > 1 else parts[0][k]) for k in parts[0]}
+        out.update(self.match(out["descriptors"], out["scores"], out.get("intensity")))
+        if vit_in is not None:
+            out["vit_input_last_chunk"] = vit_in
+        return out

@@ -1,0 +1,184 @@
+"""CPU tests of the drop-in boundary: the reference's class / method / state_dict surface, the
+autograd-capable torch-op path of the modules (used by train.py) against the reference's golden vectors,
+and the C-ABI library's export table.  No GPU compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class TokenDino(torch.nn.Module):
+    """stand-in ViT that returns the tokens it was handed (same device as timm would be used in the reference)"""
+
+    def __init__(self):
+        super().__init__()
+        self.anchor = torch.nn.Parameter(torch.zeros(1))
+        self.embed_dim = 384
+        self.tokens = None
+
+    def forward_features(self, images):
+        return self.tokens
+
+
+def test_library_exports_every_declared_symbol():
+    from sslam_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "sslam_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    L = lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/sslam_hip.h but not exported"
+    assert sorted(lib.EXPORTS) == declared
+    assert L.sslam_arch() == b"gfx950" and L.sslam_version() >= 100
+
+
+def test_host_side_packing_and_tables():
+    from sslam_amd import lib
+    from oracle import ora
+    w = synth.selector_state(0)["conv.0.weight"]
+    p = lib.pack_conv3x3(w).reshape(9, 12, 256, 32)
+    # stage (tap, chunk) holds [n][32 k] with k permuted (0,2,4,6,1,3,5,7) inside groups of 8
+    perm = np.array([0, 2, 4, 6, 1, 3, 5, 7])
+    for tap, chunk, n in [(0, 0, 0), (4, 7, 100), (8, 11, 255)]:
+        want = w[n, chunk * 32:(chunk + 1) * 32, tap // 3, tap % 3].reshape(4, 8)[:, perm].reshape(-1)
+        assert np.array_equal(p[tap, chunk, n], want)
+    ws = ora.refiner_weight_list(synth.refiner_state(0), 2)
+    packed = lib.pack_refiner(ws, 2)
+    lay = lib.refiner_layout(2)
+    assert packed.size == lay.total == 791552                      # 791 552 parameters
+    assert np.array_equal(packed[lay.in_b:lay.in_b + 384], ws[1])
+    assert np.array_equal(packed[lay.out_b:lay.out_b + 128], ws[-1])
+    # Pillow coefficient tables: identical to what the oracle derives (checked end-to-end against PIL goldens there)
+    b, c, k = lib.resample_table(640, 448, False)
+    assert k == 5 and b.shape == (896,) and c.shape == (448 * 5,)
+    assert c.reshape(448, 5).sum(axis=1).min() >= (1 << 22) - 3 and c.reshape(448, 5).sum(axis=1).max() <= (1 << 22) + 3
+    b, c, k = lib.resample_table(480, 480, True)                   # same size: identity taps
+    assert all(c.reshape(480, k)[i, b[2 * i + 1] - 1 if b[2 * i] + b[2 * i + 1] == 480 and i > 470 else (i - b[2 * i])] == 1 << 22
+               for i in (0, 5, 200, 479))
+    with pytest.raises(ValueError):
+        lib.resample_table(0, 10, False)
+
+
+def test_state_dict_surface_matches_reference():
+    from models.descriptor_refiner import DescriptorRefiner
+    from models.keypoint_selector import KeypointSelector
+    sel = KeypointSelector(384, 256)
+    assert list(sel.state_dict().keys()) == ["conv.0.weight", "conv.0.bias", "conv.2.weight", "conv.2.bias"]
+    assert sel.state_dict()["conv.0.weight"].shape == (256, 384, 3, 3)
+    assert KeypointSelector().conv[0].out_channels == 128          # class default, keypoint_selector.py:25
+    ref = DescriptorRefiner(384, 384, 128)
+    keys = list(ref.state_dict().keys())
+    want = ["input_proj.weight", "input_proj.bias"]
+    for i in range(2):
+        for m in ("norm1", "fc1", "norm2", "fc2"):
+            want += [f"residual_blocks.{i}.{m}.weight", f"residual_blocks.{i}.{m}.bias"]
+    want += ["output_proj.weight", "output_proj.bias"]
+    assert keys == want
+    assert sum(p.numel() for p in ref.parameters()) == 791552
+    assert sum(p.numel() for p in sel.parameters()) == 885249
+    # loads a checkpoint written with the reference's key names (train.py:582-592)
+    sel.load_state_dict({k: t(v) for k, v in synth.selector_state(0).items()})
+    ref.load_state_dict({k: t(v) for k, v in synth.refiner_state(0).items()})
+
+
+def _backbone(grid):
+    from models.dino_backbone import DinoBackbone
+    bb = DinoBackbone(input_size=grid * 16, freeze=True, dino=TokenDino())
+    assert (bb.embed_dim, bb.patch_size, bb.grid_h, bb.grid_w, bb.num_patches, bb.n_storage_tokens) == (384, 16, grid, grid, grid * grid, 4)
+    return bb
+
+
+def test_backbone_batchnorm_modes_cpu_path():
+    g = gold("bn_tokens")
+    tok = synth.tokens(0, 28, batch=2)
+    bb = _backbone(28)
+    assert bb._is_frozen()
+    bb.dino.tokens = t(tok[:1])
+    with torch.no_grad():
+        y = bb(torch.zeros(1, 3, 448, 448))                        # train mode by default, like the visualize_* scripts
+    assert y.shape == (1, 28, 28, 384)
+    assert np.abs(y.numpy().reshape(784, 384)[::13] - g["train_b1_f0_sub"][0]).max() < 1e-5
+    assert np.abs(bb.feature_norm.running_var.numpy() - g["train_b1_f0_running_var"]).max() < 1e-5
+    bb2 = _backbone(28).eval()
+    bb2.dino.tokens = t(tok)
+    with torch.no_grad():
+        y2 = bb2(torch.zeros(2, 3, 448, 448))
+    assert np.array_equal(y2.numpy().reshape(2, 784, 384)[:, ::13], g["eval_b2_sub"])
+    bb.dino.tokens = t(tok[:, :700])
+    with pytest.raises(AssertionError):
+        bb(torch.zeros(2, 3, 448, 448))                            # dino_backbone.py:94
+
+
+def test_selector_and_refiner_cpu_path_against_golden():
+    from models.descriptor_refiner import DescriptorRefiner
+    from models.keypoint_selector import KeypointSelector
+    from oracle import ora
+    gs, gr, gc = gold("selector"), gold("gather_refine"), gold("select_cases")
+    feat = t(ora.bn_tokens(synth.tokens(1, 28))[0].reshape(1, 28, 28, 384))
+    sel = KeypointSelector(384, 256).eval()
+    sel.load_state_dict({k: t(v) for k, v in synth.selector_state(0).items()})
+    with torch.no_grad():
+        sal = sel(feat)
+        assert sal.shape == (1, 28, 28, 1)
+        assert np.abs(sal[0, :, :, 0].numpy() - gs["g28_saliency"]).max() < 2e-6
+        kp, sc = sel.select_keypoints(t(gs["g28_saliency"]).reshape(1, 28, 28, 1), 500)
+        assert kp.shape == (1, 500, 2) and kp.dtype == torch.float32 and sc.shape == (1, 500)
+        assert np.array_equal(kp[0].numpy(), gs["g28_kp"]) and np.array_equal(sc[0].numpy(), gs["g28_scores"])
+        assert np.array_equal(sel._apply_nms(t(gs["g28_saliency"])[None], 2)[0].numpy(), gs["g28_nms"])
+        for tag in bytes(gc["tags"]).decode().split(","):
+            m = gc[tag + "_map"]
+            kp, sc = sel.select_keypoints(t(m).reshape(1, *m.shape, 1), int(gc[tag + "_K"]), int(gc[tag + "_radius"]),
+                                          float(gc[tag + "_pct"]))
+            assert np.array_equal(kp[0].numpy(), gc[tag + "_kp"]), tag
+            assert np.array_equal(sc[0].numpy(), gc[tag + "_scores"]), tag
+        with pytest.raises(RuntimeError):
+            sel.select_keypoints(t(gc["Belse_r2_map"]).reshape(1, 28, 28, 1), 28 * 28 + 200)
+    ref = DescriptorRefiner(384, 384, 128).eval()
+    ref.load_state_dict({k: t(v) for k, v in synth.refiner_state(0).items()})
+    bb = _backbone(28)
+    with torch.no_grad():
+        samp = bb.extract_at_keypoints(feat, t(gs["g28_kp"])[None])
+        assert np.abs(samp[0, ::10].numpy() - gr["g28_sampled_sub"]).max() < 2e-5
+        desc = ref(samp)
+        assert desc.shape == (1, 500, 128)
+        assert np.abs(desc[0].numpy() - gr["g28_desc"]).max() < 5e-6
+        assert np.array_equal(bb.patch_to_pixel(t(gs["g28_kp"])).numpy(), gr["g28_pix"])
+        assert np.array_equal(bb.pixel_to_patch(t(gr["g28_pix"])).numpy(), gr["g28_pix_back"])
+
+
+def test_training_step_runs_through_the_drop_in_modules():
+    """What train.py does (train.py:299-329, 239-244): grads reach selector and refiner, AdamW steps."""
+    from models.descriptor_refiner import DescriptorRefiner
+    from models.keypoint_selector import KeypointSelector
+    torch.manual_seed(0)
+    bb = _backbone(28)
+    sel, ref = KeypointSelector(384, 256), DescriptorRefiner(384, 384, 128)
+    opt = torch.optim.AdamW(list(sel.parameters()) + list(ref.parameters()), lr=1e-3)
+    bb.dino.tokens = t(synth.tokens(5, 28, batch=2))
+    with torch.no_grad():
+        feat = bb(torch.zeros(2, 3, 448, 448))
+    sal = sel(feat)
+    kp, sc = sel.select_keypoints(sal, 64)
+    desc = ref(bb.extract_at_keypoints(feat, kp))
+    loss = sal.mean() + desc.var()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(sel.parameters(), 1.0)
+    assert sel.conv[0].weight.grad is not None and ref.input_proj.weight.grad is not None
+    before = ref.output_proj.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, ref.output_proj.weight)

@@ -290,3 +290,32 @@ def test_canonical_exp_accuracy():
     assert np.max(np.abs(got - ref) / ref) < 2.5e-7
     assert ora.sigmoid(0.0) == np.float32(0.5)
     assert ora.sigmoid(-200.0) >= 0 and ora.sigmoid(200.0) == np.float32(1.0)
+
+
+# --------------------------------------------------------------------------------------------- M2 / M3 / M4
+@pytest.mark.parametrize("tag", ["p500", "p500x480", "p1024", "p33x70"])
+def test_ratio_test_matchers(tag):
+    g = gold("matchers")
+    seed, n, m, dup = (int(v) for v in g[f"{tag}_spec"])
+    d1, d2, *_ = _pair(seed, n, m, dup)
+    m2 = ora.find_matches_m2(d1, d2, 0.8)
+    assert np.array_equal(np.array([(a, b) for a, b, _ in m2], np.int64).reshape(-1, 2), g[f"{tag}_m2_ij"])
+    if m2:
+        assert np.abs(np.array([c for *_, c in m2], np.float32) - g[f"{tag}_m2_sim"]).max() < 1e-6
+    m4, dist = ora.find_mnn_m4(d1, d2, 0.9)
+    assert np.array_equal(m4, g[f"{tag}_m4_matches"])
+    if len(dist):
+        assert np.abs(dist - g[f"{tag}_m4_dist"]).max() < 1e-6
+
+
+def test_batched_mnn_padding_m3():
+    # train.py:410-449: per-sample mutual-NN pairs, zero-padded to the longest
+    g = gold("matchers")
+    want = g["m3_matches"]
+    for b, (seed, noise) in enumerate(zip(g["m3_seeds"], g["m3_noise"])):
+        d1, d2, *_ = _pair(int(seed), 200, 200, 10, float(noise))
+        nn12, _, nn21, _ = ora.sim_argmax(d1, d2)
+        idx1 = np.nonzero(nn21[nn12] == np.arange(200))[0]
+        got = np.stack([idx1, nn12[idx1]], axis=1)
+        assert np.array_equal(got, want[b, :len(got)])
+        assert not want[b, len(got):].any()
