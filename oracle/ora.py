@@ -30,9 +30,30 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU box exposes
+    256 logical CPUs but grants a 16-CPU share; 256 spinning OpenMP threads on 16 CPUs would be meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        os.environ.setdefault("OMP_NUM_THREADS", str(host_threads()))
         _lib = C.CDLL(build())
         _lib.ora_quantile.restype = C.c_float
         _lib.ora_quantile.argtypes = [C.c_void_p, C.c_int, C.c_double]

@@ -82,66 +82,89 @@ typedef struct {
 
 static const float ZEROS[ORA_C] = {0};
 
+/* Blocking: K is walked one segment at a time (the accumulators round-trip through C between segments, which
+ * continues the SAME chain: a stored fp32 is reloaded unchanged), B is re-packed into contiguous column panels. */
+static void micro_4xN(const float *const a[4], int klen, const float *bp, int w, float *c, int ldc, int mr,
+                      const float *init /* bias slice or NULL: continue from C */, int first) {
+#ifdef ORA_AVX2
+#define ORA_TILE(NV)                                                                                           \
+    {                                                                                                          \
+        __m256 acc[4][NV];                                                                                     \
+        for (int i = 0; i < 4; i++)                                                                            \
+            for (int v = 0; v < NV; v++)                                                                       \
+                acc[i][v] = first ? (init ? _mm256_loadu_ps(init + 8 * v) : _mm256_setzero_ps())               \
+                                  : _mm256_loadu_ps(c + (size_t)(i < mr ? i : 0) * ldc + 8 * v);               \
+        const float *b = bp;                                                                                   \
+        for (int k = 0; k < klen; k++, b += 8 * NV) {                                                          \
+            __m256 bv[NV];                                                                                     \
+            for (int v = 0; v < NV; v++) bv[v] = _mm256_loadu_ps(b + 8 * v);                                   \
+            const __m256 x0 = _mm256_broadcast_ss(a[0] + k), x1 = _mm256_broadcast_ss(a[1] + k);               \
+            const __m256 x2 = _mm256_broadcast_ss(a[2] + k), x3 = _mm256_broadcast_ss(a[3] + k);               \
+            for (int v = 0; v < NV; v++) {                                                                     \
+                acc[0][v] = _mm256_fmadd_ps(x0, bv[v], acc[0][v]);                                             \
+                acc[1][v] = _mm256_fmadd_ps(x1, bv[v], acc[1][v]);                                             \
+                acc[2][v] = _mm256_fmadd_ps(x2, bv[v], acc[2][v]);                                             \
+                acc[3][v] = _mm256_fmadd_ps(x3, bv[v], acc[3][v]);                                             \
+            }                                                                                                  \
+        }                                                                                                      \
+        for (int i = 0; i < mr; i++)                                                                           \
+            for (int v = 0; v < NV; v++) _mm256_storeu_ps(c + (size_t)i * ldc + 8 * v, acc[i][v]);             \
+        return;                                                                                                \
+    }
+    if (w == 24) ORA_TILE(3)
+    if (w == 16) ORA_TILE(2)
+    if (w == 8) ORA_TILE(1)
+#undef ORA_TILE
+#endif
+    for (int i = 0; i < mr; i++)
+        for (int j = 0; j < w; j++) {
+            float acc = first ? (init ? init[j] : 0.0f) : c[(size_t)i * ldc + j];
+            for (int k = 0; k < klen; k++) acc = fmaf(a[i][k], bp[(size_t)k * w + j], acc);
+            c[(size_t)i * ldc + j] = acc;
+        }
+}
+
 static void chain_gemm(const arows_t *A, int rows, const float *Bt, int N, const float *bias, float *C, int ldc) {
     const int nseg = A->nseg, seglen = A->seglen;
-#pragma omp parallel for schedule(static)
-    for (int i0 = 0; i0 < rows; i0 += 4) {
-        const int mr = rows - i0 < 4 ? rows - i0 : 4;
-        const float *const *s[4];
-        for (int i = 0; i < 4; i++) s[i] = A->seg + (size_t)(i0 + (i < mr ? i : 0)) * nseg;
-        int j0 = 0;
-#ifdef ORA_AVX2
-        for (; j0 + 24 <= N; j0 += 24) {
-            __m256 acc[4][3];
-            for (int i = 0; i < 4; i++)
-                for (int v = 0; v < 3; v++)
-                    acc[i][v] = bias ? _mm256_loadu_ps(bias + j0 + 8 * v) : _mm256_setzero_ps();
-            for (int sg = 0; sg < nseg; sg++) {
-                const float *a0 = s[0][sg] ? s[0][sg] : ZEROS, *a1 = s[1][sg] ? s[1][sg] : ZEROS;
-                const float *a2 = s[2][sg] ? s[2][sg] : ZEROS, *a3 = s[3][sg] ? s[3][sg] : ZEROS;
-                const float *b = Bt + (size_t)sg * seglen * N + j0;
-                for (int k = 0; k < seglen; k++, b += N) {
-                    __m256 b0 = _mm256_loadu_ps(b), b1 = _mm256_loadu_ps(b + 8), b2 = _mm256_loadu_ps(b + 16);
-                    __m256 x;
-                    x = _mm256_broadcast_ss(a0 + k);
-                    acc[0][0] = _mm256_fmadd_ps(x, b0, acc[0][0]);
-                    acc[0][1] = _mm256_fmadd_ps(x, b1, acc[0][1]);
-                    acc[0][2] = _mm256_fmadd_ps(x, b2, acc[0][2]);
-                    x = _mm256_broadcast_ss(a1 + k);
-                    acc[1][0] = _mm256_fmadd_ps(x, b0, acc[1][0]);
-                    acc[1][1] = _mm256_fmadd_ps(x, b1, acc[1][1]);
-                    acc[1][2] = _mm256_fmadd_ps(x, b2, acc[1][2]);
-                    x = _mm256_broadcast_ss(a2 + k);
-                    acc[2][0] = _mm256_fmadd_ps(x, b0, acc[2][0]);
-                    acc[2][1] = _mm256_fmadd_ps(x, b1, acc[2][1]);
-                    acc[2][2] = _mm256_fmadd_ps(x, b2, acc[2][2]);
-                    x = _mm256_broadcast_ss(a3 + k);
-                    acc[3][0] = _mm256_fmadd_ps(x, b0, acc[3][0]);
-                    acc[3][1] = _mm256_fmadd_ps(x, b1, acc[3][1]);
-                    acc[3][2] = _mm256_fmadd_ps(x, b2, acc[3][2]);
-                }
-            }
-            for (int i = 0; i < mr; i++)
-                for (int v = 0; v < 3; v++) _mm256_storeu_ps(C + (size_t)(i0 + i) * ldc + j0 + 8 * v, acc[i][v]);
-        }
-#endif
-        for (; j0 < N; j0 += 8) {
-            const int nr = N - j0 < 8 ? N - j0 : 8;
-            float acc[4][8];
-            for (int i = 0; i < 4; i++)
-                for (int j = 0; j < 8; j++) acc[i][j] = (bias && j < nr) ? bias[j0 + j] : 0.0f;
-            for (int sg = 0; sg < nseg; sg++) {
-                const float *a[4];
-                for (int i = 0; i < 4; i++) a[i] = s[i][sg] ? s[i][sg] : ZEROS;
-                const float *b = Bt + (size_t)sg * seglen * N + j0;
-                for (int k = 0; k < seglen; k++, b += N)
-                    for (int i = 0; i < 4; i++)
-                        for (int j = 0; j < nr; j++) acc[i][j] = fmaf(a[i][k], b[j], acc[i][j]);
-            }
-            for (int i = 0; i < mr; i++)
-                for (int j = 0; j < nr; j++) C[(size_t)(i0 + i) * ldc + j0 + j] = acc[i][j];
-        }
+    /* column panels: widths 24,24,...,then 16 / 8 / remainder */
+    int pw[512], po[512], np = 0;
+    for (int j = 0; j < N;) {
+        const int left = N - j;
+        const int w = left >= 24 ? 24 : (left >= 16 ? 16 : (left >= 8 ? 8 : left));
+        po[np] = j; pw[np] = w; np++; j += w;
     }
+    /* Bp[sg][panel][k][w] */
+    float *Bp = (float *)malloc((size_t)nseg * seglen * N * sizeof(float));
+    size_t *boff = (size_t *)malloc((size_t)nseg * np * sizeof(size_t));
+    {
+        size_t off = 0;
+        for (int sg = 0; sg < nseg; sg++)
+            for (int p = 0; p < np; p++) {
+                boff[(size_t)sg * np + p] = off;
+                for (int k = 0; k < seglen; k++)
+                    memcpy(Bp + off + (size_t)k * pw[p], Bt + ((size_t)sg * seglen + k) * N + po[p], (size_t)pw[p] * sizeof(float));
+                off += (size_t)seglen * pw[p];
+            }
+    }
+    const int MC = 32;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int rb = 0; rb < rows; rb += MC) {
+        const int rend = rb + MC < rows ? rb + MC : rows;
+        for (int sg = 0; sg < nseg; sg++)
+            for (int p = 0; p < np; p++)
+                for (int i0 = rb; i0 < rend; i0 += 4) {
+                    const int mr = rend - i0 < 4 ? rend - i0 : 4;
+                    const float *a[4];
+                    for (int i = 0; i < 4; i++) {
+                        const float *q = A->seg[(size_t)(i0 + (i < mr ? i : 0)) * nseg + sg];
+                        a[i] = q ? q : ZEROS;
+                    }
+                    micro_4xN(a, seglen, Bp + boff[(size_t)sg * np + p], pw[p], C + (size_t)i0 * ldc + po[p], ldc, mr,
+                              bias ? bias + po[p] : NULL, sg == 0);
+                }
+    }
+    free(boff);
+    free(Bp);
 }
 
 /* Bt[k][n] = W[n][k] */
@@ -182,8 +205,8 @@ void ora_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int 
             memset(P, 0, 16 * sizeof(*P));
             for (int r = 0; r < R; r++) {
                 const int f = g * group + r / cells, t = n_prefix + r % cells;
-                const float *x = tokens + ((size_t)f * tokens_per_frame + t) * ORA_C;
-                float *p = P[r & 15];
+                const float *__restrict x = tokens + ((size_t)f * tokens_per_frame + t) * ORA_C;
+                float *__restrict p = P[r & 15];
                 for (int c = 0; c < ORA_C; c++) p[c] = p[c] + x[c];
             }
             for (int c = 0; c < ORA_C; c++) {
@@ -194,8 +217,8 @@ void ora_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int 
             memset(P, 0, 16 * sizeof(*P));
             for (int r = 0; r < R; r++) {
                 const int f = g * group + r / cells, t = n_prefix + r % cells;
-                const float *x = tokens + ((size_t)f * tokens_per_frame + t) * ORA_C;
-                float *p = P[r & 15];
+                const float *__restrict x = tokens + ((size_t)f * tokens_per_frame + t) * ORA_C;
+                float *__restrict p = P[r & 15];
                 for (int c = 0; c < ORA_C; c++) {
                     const float d = x[c] - mean[c];
                     p[c] = fmaf(d, d, p[c]);
@@ -221,8 +244,8 @@ void ora_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int 
         }
         for (int r = 0; r < R; r++) {
             const int f = g * group + r / cells, t = r % cells;
-            const float *x = tokens + ((size_t)f * tokens_per_frame + n_prefix + t) * ORA_C;
-            float *y = out_feat + ((size_t)f * cells + t) * ORA_C;
+            const float *__restrict x = tokens + ((size_t)f * tokens_per_frame + n_prefix + t) * ORA_C;
+            float *__restrict y = out_feat + ((size_t)f * cells + t) * ORA_C;
             for (int c = 0; c < ORA_C; c++) y[c] = x[c] * alpha[c] + bshift[c];
         }
     }
