@@ -48,7 +48,7 @@ long long sslam_launch_count(void);
  * sslam_pack_conv3x3_host: w (hs,384,3,3) [keypoint_selector.py:31, state_dict key conv.0.weight]
  *                          -> out (9*384*hs floats).
  * sslam_pack_linear_host:  w (n_out, k_in) [nn.Linear weight, descriptor_refiner.py:35,43,103,105]
- *                          -> out (n_out*k_in floats); k_in % 16 == 0. */
+ *                          -> out (n_out*k_in floats) as [k/8][n][8]; k_in % 8 == 0. */
 int sslam_pack_conv3x3_host(const float *w_host, int hs, float *out_host);
 int sslam_pack_linear_host(const float *w_host, int n_out, int k_in, float *out_host);
 

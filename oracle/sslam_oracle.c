@@ -85,7 +85,7 @@ static const float ZEROS[ORA_C] = {0};
 /* Blocking: K is walked one segment at a time (the accumulators round-trip through C between segments, which
  * continues the SAME chain: a stored fp32 is reloaded unchanged), B is re-packed into contiguous column panels. */
 static void micro_4xN(const float *const a[4], int klen, const float *bp, int w, float *c, int ldc, int mr,
-                      const float *init /* bias slice or NULL: continue from C */, int first) {
+                      const float *init /* bias slice or NULL */, int first) {
 #ifdef ORA_AVX2
 #define ORA_TILE(NV)                                                                                           \
     {                                                                                                          \
@@ -125,7 +125,9 @@ static void micro_4xN(const float *const a[4], int klen, const float *bp, int w,
 }
 
 static void chain_gemm(const arows_t *A, int rows, const float *Bt, int N, const float *bias, float *C, int ldc) {
-    const int nseg = A->nseg, seglen = A->seglen;
+    const int nseg = A->nseg, seglen = A->seglen, K = nseg * seglen;
+    const int KC = 384;                                   /* K block: accumulators round-trip through C in between */
+    const int nblk = (K + KC - 1) / KC;
     /* column panels: widths 24,24,...,then 16 / 8 / remainder */
     int pw[512], po[512], np = 0;
     for (int j = 0; j < N;) {
@@ -133,35 +135,51 @@ static void chain_gemm(const arows_t *A, int rows, const float *Bt, int N, const
         const int w = left >= 24 ? 24 : (left >= 16 ? 16 : (left >= 8 ? 8 : left));
         po[np] = j; pw[np] = w; np++; j += w;
     }
-    /* Bp[sg][panel][k][w] */
-    float *Bp = (float *)malloc((size_t)nseg * seglen * N * sizeof(float));
-    size_t *boff = (size_t *)malloc((size_t)nseg * np * sizeof(size_t));
+    /* Bp[blk][panel][k in block][w] */
+    float *Bp = (float *)malloc((size_t)K * N * sizeof(float));
+    size_t *boff = (size_t *)malloc((size_t)nblk * np * sizeof(size_t));
     {
         size_t off = 0;
-        for (int sg = 0; sg < nseg; sg++)
+        for (int b = 0; b < nblk; b++) {
+            const int k0 = b * KC, kl = k0 + KC <= K ? KC : K - k0;
             for (int p = 0; p < np; p++) {
-                boff[(size_t)sg * np + p] = off;
-                for (int k = 0; k < seglen; k++)
-                    memcpy(Bp + off + (size_t)k * pw[p], Bt + ((size_t)sg * seglen + k) * N + po[p], (size_t)pw[p] * sizeof(float));
-                off += (size_t)seglen * pw[p];
+                boff[(size_t)b * np + p] = off;
+                for (int k = 0; k < kl; k++)
+                    memcpy(Bp + off + (size_t)k * pw[p], Bt + (size_t)(k0 + k) * N + po[p], (size_t)pw[p] * sizeof(float));
+                off += (size_t)kl * pw[p];
             }
+        }
     }
     const int MC = 32;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int rb = 0; rb < rows; rb += MC) {
-        const int rend = rb + MC < rows ? rb + MC : rows;
-        for (int sg = 0; sg < nseg; sg++)
-            for (int p = 0; p < np; p++)
-                for (int i0 = rb; i0 < rend; i0 += 4) {
-                    const int mr = rend - i0 < 4 ? rend - i0 : 4;
-                    const float *a[4];
-                    for (int i = 0; i < 4; i++) {
-                        const float *q = A->seg[(size_t)(i0 + (i < mr ? i : 0)) * nseg + sg];
-                        a[i] = q ? q : ZEROS;
+#pragma omp parallel
+    {
+        /* segmented rows (the conv's shifted / zero-padded taps) are packed into contiguous K-ordered rows per block */
+        float *Ap = nseg > 1 ? (float *)malloc((size_t)MC * K * sizeof(float)) : NULL;
+#pragma omp for schedule(dynamic, 1)
+        for (int rb = 0; rb < rows; rb += MC) {
+            const int rend = rb + MC < rows ? rb + MC : rows;
+            if (Ap)
+                for (int i = rb; i < rend; i++)
+                    for (int sg = 0; sg < nseg; sg++) {
+                        const float *q = A->seg[(size_t)i * nseg + sg];
+                        memcpy(Ap + (size_t)(i - rb) * K + (size_t)sg * seglen, q ? q : ZEROS, (size_t)seglen * sizeof(float));
                     }
-                    micro_4xN(a, seglen, Bp + boff[(size_t)sg * np + p], pw[p], C + (size_t)i0 * ldc + po[p], ldc, mr,
-                              bias ? bias + po[p] : NULL, sg == 0);
-                }
+            for (int b = 0; b < nblk; b++) {
+                const int k0 = b * KC, kl = k0 + KC <= K ? KC : K - k0;
+                for (int p = 0; p < np; p++)
+                    for (int i0 = rb; i0 < rend; i0 += 4) {
+                        const int mr = rend - i0 < 4 ? rend - i0 : 4;
+                        const float *a[4];
+                        for (int i = 0; i < 4; i++) {
+                            const int ri = i0 + (i < mr ? i : 0);
+                            a[i] = (Ap ? Ap + (size_t)(ri - rb) * K : A->seg[ri]) + k0;
+                        }
+                        micro_4xN(a, kl, Bp + boff[(size_t)b * np + p], pw[p], C + (size_t)i0 * ldc + po[p], ldc, mr,
+                                  bias ? bias + po[p] : NULL, b == 0);
+                    }
+            }
+        }
+        free(Ap);
     }
     free(boff);
     free(Bp);
@@ -253,36 +271,35 @@ void ora_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int 
 
 /* ------------------------------------------------------------------------------------------------------
  * A3  saliency CNN (keypoint_selector.py:45-67)
- *   hidden[n] = fmaf chain from b1[n] over k = tap*384 + c, tap = ky*3 + kx (zero taps included), then ReLU.
+ *   hidden[n] = fmaf chain from b1[n] over k = (chunk*9 + tap)*32 + cc  (channel c = chunk*32 + cc, tap = ky*3 + kx;
+ *   the nine taps of a 32-channel slice are consecutive; zero taps included), then ReLU.
  *   logit: p[n] = hidden[n] * w2[n];  for each 64-wide slab s: q[c] = p[64s + c] + p[64s + 32 + c] (c < 32),
  *   T_s = butterfly32(q);  logit = ((b2 + T_0) + T_1) + ...;  saliency = 1 / (1 + ora_expf(-logit)).
  * ---------------------------------------------------------------------------------------------------- */
 void ora_selector_saliency(const float *feat, int n_frames, int G, const float *w1, const float *b1,
                            const float *w2, const float *b2, int hs, float *sal) {
-    const int cells = G * G, K = 9 * ORA_C;
-    /* Bt[(tap*384 + c)][n] = w1[n][c][ky][kx] */
+    const int cells = G * G, K = 9 * ORA_C, NSEG = 108, SEGLEN = 32;
+    /* canonical k order: k = (chunk*9 + tap)*32 + cc with channel c = chunk*32 + cc, tap = ky*3 + kx */
     float *Bt = (float *)malloc((size_t)K * hs * sizeof(float));
     for (int n = 0; n < hs; n++)
         for (int c = 0; c < ORA_C; c++)
-            for (int t = 0; t < 9; t++) Bt[((size_t)t * ORA_C + c) * hs + n] = w1[((size_t)n * ORA_C + c) * 9 + t];
+            for (int t = 0; t < 9; t++)
+                Bt[((size_t)((c / SEGLEN) * 9 + t) * SEGLEN + c % SEGLEN) * hs + n] = w1[((size_t)n * ORA_C + c) * 9 + t];
     const int rows = n_frames * cells;
-    const float **seg = (const float **)malloc((size_t)rows * 9 * sizeof(float *));
-    for (int m = 0; m < rows; m++) {
-        const int f = m / cells, cell = m % cells, y = cell / G, x = cell % G;
-        for (int t = 0; t < 9; t++) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            seg[(size_t)m * 9 + t] =
-                (yy < 0 || yy >= G || xx < 0 || xx >= G) ? NULL : feat + (((size_t)f * G + yy) * G + xx) * ORA_C;
-        }
-    }
-    arows_t A = {seg, 9, ORA_C};
-    /* process in row blocks to bound the hidden buffer */
-    const int RB = 4096;
+    const int RB = 4096;   /* row blocks bound the hidden buffer and the segment table */
+    const float **seg = (const float **)malloc((size_t)RB * NSEG * sizeof(float *));
     float *hid = (float *)malloc((size_t)RB * hs * sizeof(float));
     for (int r0 = 0; r0 < rows; r0 += RB) {
         const int nr = rows - r0 < RB ? rows - r0 : RB;
-        arows_t Ab = {seg + (size_t)r0 * 9, 9, ORA_C};
-        (void)A;
+        for (int i = 0; i < nr; i++) {
+            const int m = r0 + i, f = m / cells, cell = m % cells, y = cell / G, x = cell % G;
+            for (int t = 0; t < 9; t++) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const float *row = (yy < 0 || yy >= G || xx < 0 || xx >= G) ? NULL : feat + (((size_t)f * G + yy) * G + xx) * ORA_C;
+                for (int ch = 0; ch < ORA_C / SEGLEN; ch++) seg[(size_t)i * NSEG + ch * 9 + t] = row ? row + ch * SEGLEN : NULL;
+            }
+        }
+        arows_t Ab = {seg, NSEG, SEGLEN};
         chain_gemm(&Ab, nr, Bt, hs, b1, hid, hs);
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < nr; i++) {

@@ -21,23 +21,35 @@ constexpr int QB = 128;            // queries per workgroup
 constexpr int CB = 64;             // candidates per stage
 constexpr int LDD = SSLAM_D + 4;   // 132-float rows: 528 B = 33 x 16 B -> conflict-free b128 fragment reads
 
-__device__ __forceinline__ void stage_rows(float *dst, const float *__restrict__ src, int first, int n_valid, int rows,
-                                           int tid) {
-    // rows x 128 floats -> KP8 image; rows beyond n_valid are zero (they are masked out of the arg-max anyway)
-    for (int it = tid; it < rows * 16; it += 512) {
-        const int row = it >> 4, g = it & 15;
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (first + row < n_valid) {
-            const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(first + row) * SSLAM_D + 8 * g);
-            lo = p[0];
-            hi = p[1];
+// rows x 128 floats -> KP8 image, split into a load half (global -> registers) and a store half (registers -> LDS)
+// so that the next candidate tile is in flight while the current one is multiplied.
+// rows beyond n_valid are zero (they are masked out of the arg-max anyway)
+template <int ROWS>
+struct Stager {
+    static constexpr int ITEMS = ROWS * 16 / 512;
+    float4 lo[ITEMS], hi[ITEMS];
+    __device__ __forceinline__ void load(const float *__restrict__ src, int first, int n_valid, int tid) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int it = tid + 512 * i, row = it >> 4, g = it & 15;
+            const bool ok = first + row < n_valid;
+            const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(ok ? first + row : 0) * SSLAM_D + 8 * g);
+            const float4 a = p[0], b = p[1];
+            lo[i] = make_float4(ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f);
+            hi[i] = make_float4(ok ? b.x : 0.f, ok ? b.y : 0.f, ok ? b.z : 0.f, ok ? b.w : 0.f);
         }
-        float4 ev, od;
-        kp8_split(lo, hi, ev, od);
-        *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g) = ev;
-        *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g + 4) = od;
     }
-}
+    __device__ __forceinline__ void store(float *dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int it = tid + 512 * i, row = it >> 4, g = it & 15;
+            float4 ev, od;
+            kp8_split(lo[i], hi[i], ev, od);
+            *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g) = ev;
+            *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g + 4) = od;
+        }
+    }
+};
 
 __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
                                                           const float *__restrict__ desc2, long long stride2, int n2,
@@ -59,8 +71,14 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
     float *o_val = dir == 0 ? (s12 ? s12 + pair * n1 : nullptr) : (s21 ? s21 + pair * n2 : nullptr);
     float *o_sec = (dir == 0 && second12) ? second12 + pair * n1 : nullptr;
 
-    stage_rows(Qs, q, q0, nq, QB, tid);
-    stage_rows(Cs, c, 0, nc, CB, tid);
+    {
+        Stager<QB> sq;
+        sq.load(q, q0, nq, tid);
+        sq.store(Qs, tid);
+    }
+    Stager<CB> sc;
+    sc.load(c, 0, nc, tid);
+    sc.store(Cs, tid);
     __syncthreads();
 
     float best = -INFINITY, second = -INFINITY;   // second: best of the row once the winner is removed
@@ -68,7 +86,7 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
     const int nstage = (nc + CB - 1) / CB;
     const float *B = Qs + (wq * 32 + r) * LDD + 4 * h;
     for (int s = 0; s < nstage; s++) {
-        if (s + 1 < nstage) stage_rows(Cs + ((s + 1) & 1) * CB * LDD, c, (s + 1) * CB, nc, CB, tid);
+        if (s + 1 < nstage) sc.load(c, (s + 1) * CB, nc, tid);     // in flight during the MFMAs below
         const float *A = Cs + (s & 1) * CB * LDD + (wc * 32 + r) * LDD + 4 * h;
         f32x16 acc;
 #pragma unroll
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
                 }
             }
         }
+        if (s + 1 < nstage) sc.store(Cs + ((s + 1) & 1) * CB * LDD, tid);
         __syncthreads();
     }
     // merge the two half-waves (same query, interleaved candidate rows), then the two candidate waves

@@ -5,8 +5,11 @@
 // One workgroup (8 waves) owns 64 keypoint rows for the WHOLE chain: gather -> input_proj+ReLU -> n_blocks x
 // {LN, fc1, ReLU, LN, fc2, +identity, ReLU} -> output_proj -> L2 normalise.  The 64x384 activation tile lives in LDS
 // (KP8 order, 388-float rows) and is the MFMA A operand directly; the residual identity stays in registers in the
-// MFMA C layout (each wave keeps the same 32x96 output sub-tile in every layer); only the pre-packed weights
-// stream in (16-deep K stages, register double-buffered, L2-resident: 3.17 MB shared by all workgroups).
+// MFMA C layout (each wave keeps the same 32x96 output sub-tile in every layer).  The pre-packed weights (3.17 MB,
+// L2-resident, shared by all workgroups) are NOT staged through LDS: they are stored in MFMA-fragment order
+// ([k/8][n][8 floats KP8]), so a wave's B fragment is one fully coalesced 1 KB global load per tile, prefetched two
+// k-groups ahead into registers.  A layer's GEMM therefore has no barrier at all - waves drift freely and keep the
+// matrix pipe busy; barriers only separate the layers (activation tile hand-over).
 // All contractions are v_mfma_f32_32x32x2_f32 chains in increasing k from the bias: bit-identical to the oracle.
 //
 // Roofline: MFMA-bound, 1 572 864 FLOP per row (786.4 MFLOP per 500-keypoint frame) against 1.5 KB in / 0.5 KB out.
@@ -14,27 +17,31 @@
 
 namespace {
 
-constexpr int RM = 64;              // rows per workgroup
+#ifndef SSLAM_REFINE_WMR
+#define SSLAM_REFINE_WMR 1
+#endif
+constexpr int WMR = SSLAM_REFINE_WMR;   // waves along M: 1 -> 32-row workgroups of 4 waves (3 co-resident per CU, so the
+                                        // gather / LayerNorm phases of one overlap the GEMMs of the others); 2 -> 64 rows
+constexpr int RM = 32 * WMR;        // rows per workgroup
+constexpr int NTHR = 256 * WMR;
 constexpr int HID = SSLAM_HID;      // 384
 constexpr int LDH = HID + 4;        // activation row stride (floats)
-constexpr int WBK = 16;             // K depth of one weight stage
-constexpr int LDW = WBK + 4;        // weight stage row stride (floats): 80 B = 5 x 16 B
-constexpr int NCHUNK = HID / WBK;   // 24 stages per layer
+constexpr int NKG = HID / 8;        // 48 k-groups of 8 per layer
 constexpr int H_FLOATS = RM * LDH;
-constexpr int W_STAGE = HID * LDW;
-constexpr int SMEM_FLOATS = H_FLOATS + 2 * W_STAGE;   // 160 768 B
+constexpr int SCRATCH_FLOATS = RM * 4;
+constexpr int SMEM_FLOATS = H_FLOATS + SCRATCH_FLOATS;   // 100 352 B
 
 struct RefArgs {
     const float *packed;
     sslam_refiner_layout_t lay;
 };
 
-// acc[t] (32 rows x 32 cols each, t-th N tile of this wave) = bias + H(64 x 384) . W^T, K walked in 24 stages
+// acc[t] (32 rows x 32 cols each, t-th N tile of this wave) = bias + H(64 x 384) . W^T, one fma chain per output in
+// increasing k.  B fragments come straight from global memory (fragment-ordered packed weights), ring of 3 k-groups.
 template <int NT>
-__device__ __forceinline__ void gemm_lds(const float *H, float *Wst, const float *__restrict__ wp,
-                                         const float *__restrict__ bias, int tid, f32x16 (&acc)[NT]) {
+__device__ __forceinline__ void gemm_lds(const float *H, const float *__restrict__ wp, const float *__restrict__ bias,
+                                         int tid, f32x16 (&acc)[NT]) {
     constexpr int N = 128 * NT;
-    constexpr int ITEMS = N * 4 / 512;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -42,44 +49,33 @@ __device__ __forceinline__ void gemm_lds(const float *H, float *Wst, const float
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = bv;
     }
-    float4 rw[ITEMS];
-    const float4 *wp4 = reinterpret_cast<const float4 *>(wp);
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) rw[i] = wp4[tid + 512 * i];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int q = tid + 512 * i;
-        *reinterpret_cast<float4 *>(Wst + (q >> 2) * LDW + (q & 3) * 4) = rw[i];
-    }
-    __syncthreads();
+    // lane's B fragment of k-group g, tile t: 16 B at ((g*N + n)*8 + 4h) floats, n = wn*32*NT + t*32 + r
+    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(wp) + ((wn * 32 * NT + r) * 2 + h);
     const float *A = H + (wm * 32 + r) * LDH + 4 * h;
-    for (int s = 0; s < NCHUNK; s++) {
-        if (s + 1 < NCHUNK) {
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) rw[i] = wp4[(long long)(s + 1) * N * 4 + tid + 512 * i];
-        }
-        const float *B = Wst + (s & 1) * W_STAGE + (wn * 32 * NT + r) * LDW + 4 * h;
-#pragma unroll
-        for (int g = 0; g < WBK / 8; g++) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(A + s * WBK + 8 * g);
-            f32x4 b[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const f32x4 *>(B + t * 32 * LDW + 8 * g);
-#pragma unroll
-            for (int st = 0; st < 4; st++)
-#pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = mfma32(a[st], b[t][st], acc[t]);
-        }
-        if (s + 1 < NCHUNK) {
-            float *W1 = Wst + ((s + 1) & 1) * W_STAGE;
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const int q = tid + 512 * i;
-                *reinterpret_cast<float4 *>(W1 + (q >> 2) * LDW + (q & 3) * 4) = rw[i];
-            }
-        }
-        __syncthreads();
+    f32x4 b0[NT], b1[NT], b2[NT];
+#define LOAD_B(dst, g)                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) dst[t] = bsrc[((g) * N + t * 32) * 2];
+#define STEP(cur, g)                                                                  \
+    {                                                                                 \
+        const f32x4 a = an;                                                           \
+        an = *reinterpret_cast<const f32x4 *>(A + 8 * (((g) + 1) < NKG ? (g) + 1 : (g))); /* next k-group's A */ \
+        _Pragma("unroll") for (int st = 0; st < 4; st++)                              \
+            _Pragma("unroll") for (int t = 0; t < NT; t++) acc[t] = mfma32(a[st], cur[t][st], acc[t]); \
     }
+    LOAD_B(b0, 0);
+    LOAD_B(b1, 1);
+    f32x4 an = *reinterpret_cast<const f32x4 *>(A);
+#pragma unroll 1
+    for (int g = 0; g < NKG; g += 3) {
+        LOAD_B(b2, g + 2);
+        STEP(b0, g);
+        if (g + 3 < NKG) LOAD_B(b0, g + 3);
+        STEP(b1, g + 1);
+        if (g + 4 < NKG) LOAD_B(b1, g + 4);
+        STEP(b2, g + 2);
+    }
+#undef LOAD_B
+#undef STEP
 }
 
 // write this wave's C-layout tiles back into the activation tile (KP8 positions)
@@ -136,7 +132,8 @@ __device__ __forceinline__ void layernorm_rows(float *H, const float *__restrict
 }
 
 struct Taps {
-    const float *src[4];
+    const float *src[4];   // always a readable address (clamped into the grid)
+    bool ok[4];            // false: the tap lies outside the grid and contributes 0 * weight (zero padding)
     float wt[4];
 };
 
@@ -149,20 +146,26 @@ __device__ __forceinline__ Taps make_taps(const float *feat_frame, int G, float 
     const float w = ix - x0, e = 1.0f - w, n = iy - y0, s = 1.0f - n;
     Taps t;
     t.wt[0] = s * e; t.wt[1] = s * w; t.wt[2] = n * e; t.wt[3] = n * w;
-    const int xi = (int)x0, yi = (int)y0;
+    // clamp in float first: far-out-of-range coordinates must not overflow the int conversion
+    const int xi = (int)fminf(fmaxf(x0, -2.0f), (float)G), yi = (int)fminf(fmaxf(y0, -2.0f), (float)G);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int xs = xi + (k & 1), ys = yi + (k >> 1);
-        t.src[k] = (xs < 0 || xs >= G || ys < 0 || ys >= G) ? nullptr : feat_frame + ((long long)ys * G + xs) * SSLAM_C;
+        t.ok[k] = !(xs < 0 || xs >= G || ys < 0 || ys >= G);
+        const int xc = min(max(xs, 0), G - 1), yc = min(max(ys, 0), G - 1);
+        t.src[k] = feat_frame + ((long long)yc * G + xc) * SSLAM_C;
     }
     return t;
 }
 
-__device__ __forceinline__ float4 ld4(const float *p, int off) {
-    return p ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+// unconditional load + select: keeps the four tap loads of a chunk in flight together (no branch per tap)
+__device__ __forceinline__ float4 ld4(const Taps &t, int k, int off) {
+    const float4 v = *reinterpret_cast<const float4 *>(t.src[k] + off);
+    const bool ok = t.ok[k];
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 __device__ __forceinline__ float4 blend4(const Taps &t, int off) {
-    const float4 a = ld4(t.src[0], off), b = ld4(t.src[1], off), c = ld4(t.src[2], off), d = ld4(t.src[3], off);
+    const float4 a = ld4(t, 0, off), b = ld4(t, 1, off), c = ld4(t, 2, off), d = ld4(t, 3, off);
     float4 o;
     o.x = ((a.x * t.wt[0] + b.x * t.wt[1]) + c.x * t.wt[2]) + d.x * t.wt[3];
     o.y = ((a.y * t.wt[0] + b.y * t.wt[1]) + c.y * t.wt[2]) + d.y * t.wt[3];
@@ -171,12 +174,12 @@ __device__ __forceinline__ float4 blend4(const Taps &t, int off) {
     return o;
 }
 
-__global__ __launch_bounds__(512) void gather_refine_kernel(const float *__restrict__ feat, int G,
+__global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(const float *__restrict__ feat, int G,
                                                              const float *__restrict__ kp_xy, int K,
                                                              const float *__restrict__ x_in, long long rows,
                                                              RefArgs args, float *__restrict__ desc) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    float *H = smem, *Wst = smem + H_FLOATS;
+    float *H = smem, *scratch = smem + H_FLOATS;
     const int tid = threadIdx.x;
     const long long R0 = (long long)blockIdx.x * RM;
     const float *pk = args.packed;
@@ -211,30 +214,34 @@ __global__ __launch_bounds__(512) void gather_refine_kernel(const float *__restr
             }
         }
     }
-    // (gemm_lds begins with a barrier after its own first weight stage is staged: H is visible by then)
+    __syncthreads();
 
     // ---- input_proj + ReLU (descriptor_refiner.py:76) -----------------------------------------------------------
     f32x16 X[3], acc[3];
-    gemm_lds<3>(H, Wst, pk + L.in_w, pk + L.in_b, tid, acc);
+    gemm_lds<3>(H, pk + L.in_w, pk + L.in_b, tid, acc);
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int e = 0; e < 16; e++) X[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
+    __syncthreads();            // every wave has finished reading the tile
     store_tile<3>(H, tid, X);
     __syncthreads();
 
     // ---- residual blocks (descriptor_refiner.py:108-126) --------------------------------------------------------
     for (int b = 0; b < L.n_blocks; b++) {
         layernorm_rows(H, pk + L.blk[b][0], pk + L.blk[b][1], tid);
-        gemm_lds<3>(H, Wst, pk + L.blk[b][2], pk + L.blk[b][3], tid, acc);
+        __syncthreads();
+        gemm_lds<3>(H, pk + L.blk[b][2], pk + L.blk[b][3], tid, acc);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
+        __syncthreads();
         store_tile<3>(H, tid, acc);
         __syncthreads();
         layernorm_rows(H, pk + L.blk[b][4], pk + L.blk[b][5], tid);
-        gemm_lds<3>(H, Wst, pk + L.blk[b][6], pk + L.blk[b][7], tid, acc);
+        __syncthreads();
+        gemm_lds<3>(H, pk + L.blk[b][6], pk + L.blk[b][7], tid, acc);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -242,16 +249,17 @@ __global__ __launch_bounds__(512) void gather_refine_kernel(const float *__restr
                 const float v = acc[t][e] + X[t][e];
                 X[t][e] = v > 0.0f ? v : 0.0f;
             }
+        __syncthreads();
         store_tile<3>(H, tid, X);
         __syncthreads();
     }
 
     // ---- output_proj + L2 normalise (:83-86; F.normalize eps 1e-12) --------------------------------------------
     f32x16 o[1];
-    gemm_lds<1>(H, Wst, pk + L.out_w, pk + L.out_b, tid, o);
+    gemm_lds<1>(H, pk + L.out_w, pk + L.out_b, tid, o);
     {
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
-        float *part = Wst;  // [64 rows][4 waves]; weight stages are idle (barrier at the end of gemm_lds)
+        float *part = scratch;  // [64 rows][4 waves]
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const float t = bfly32(o[0][e] * o[0][e]);
@@ -286,7 +294,7 @@ int launch_refine(const float *feat, int G, const float *kp_xy, int K, const flo
     a.packed = packed;
     if (sslam_refiner_layout(n_blocks, &a.lay) != SSLAM_OK) return SSLAM_E_UNSUPPORTED;
     const unsigned grid = (unsigned)((rows + RM - 1) / RM);
-    hipLaunchKernelGGL(gather_refine_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, feat, G, kp_xy, K, x_in, rows,
+    hipLaunchKernelGGL(gather_refine_kernel, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, feat, G, kp_xy, K, x_in, rows,
                        a, desc);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
@@ -315,12 +323,12 @@ extern "C" int sslam_refiner_layout(int n_blocks, sslam_refiner_layout_t *L) {
     return SSLAM_OK;
 }
 
-// w (n_out, k_in) -> [chunk = k/16][n][16 floats in KP8 order]
+// w (n_out, k_in) -> [k-group = k/8][n][8 floats in KP8 order]: the MFMA B-fragment order
 extern "C" int sslam_pack_linear_host(const float *w, int n_out, int k_in, float *out) {
-    if (!w || !out || n_out <= 0 || k_in <= 0 || (k_in % WBK)) return SSLAM_E_INVALID;
+    if (!w || !out || n_out <= 0 || k_in <= 0 || (k_in % 8)) return SSLAM_E_INVALID;
     for (int n = 0; n < n_out; n++)
         for (int k = 0; k < k_in; k++)
-            out[((long long)(k / WBK) * n_out + n) * WBK + kp8(k % WBK)] = w[(long long)n * k_in + k];
+            out[((long long)(k / 8) * n_out + n) * 8 + kp8(k % 8)] = w[(long long)n * k_in + k];
     return SSLAM_OK;
 }
 

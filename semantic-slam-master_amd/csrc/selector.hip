@@ -1,45 +1,63 @@
 // selector.hip - A3: saliency CNN (conv3x3 384->hs + ReLU + conv1x1 hs->1 + sigmoid) as one fp32-MFMA implicit GEMM.
 // Replaces KeypointSelector.forward (reference semantic-slam/models/keypoint_selector.py:45-67).
 //
-// GEMM view: M = n_frames*G*G cells, N = hs hidden channels, K = 9 taps * 384 channels (k = tap*384 + c).
-// Workgroup = 8 waves, tile BM x hs with every wave owning a 64x64 sub-tile (2x2 MFMA 32x32 tiles):
-//   hs = 256: waves 2(M) x 4(N), BM = 128;   hs = 128: waves 4(M) x 2(N), BM = 256.
-// K is walked in 108 stages of 32 (tap-major), A rows are gathered from the NHWC feature map with the tap's
-// spatial shift (zero rows outside the grid are multiplied through, exactly as the oracle does), B comes from the
-// pre-packed weight image.  Both operands are staged through LDS in the KP8 order (common.h) with a +4 float row
-// pad: one conflict-free ds_read_b128 then feeds four consecutive v_mfma_f32_32x32x2_f32 steps.
-// Global->LDS staging is register double-buffered: the loads of stage s+1 are in flight while stage s computes.
+// GEMM view: M = n_frames*G*G cells, N = hs hidden channels, K = 3456 walked in 108 stages of 32 in the canonical
+// order k = (chunk*9 + tap)*32 + c, chunk = 32-channel slice (0..11), tap = ky*3 + kx: the nine taps of one channel
+// slice are consecutive, so a workgroup re-reads the same (BM + 2G + 2) x 128 B window nine times in a row - L1/L2
+// hits instead of nine sweeps over the feature map (which measured 8.8x the algorithmic HBM bytes).
+// Workgroup = 8 waves; every wave owns a 64 x (32*NI) sub-tile (2 x NI MFMA 32x32 tiles).  A rows are gathered from
+// the NHWC feature map with the tap's spatial shift (zero rows outside the grid are multiplied through, exactly as
+// the oracle does) and staged through LDS in the KP8 order (common.h) with a +4 float row pad: one conflict-free
+// ds_read_b128 feeds four consecutive v_mfma_f32_32x32x2_f32 steps.  B (the pre-packed weights, MFMA-fragment order
+// [stage][k-group][n][8]) is either staged through LDS too or, BDIRECT, loaded straight from L2 into registers
+// (1 KB coalesced per wave-instruction).  Global->LDS staging is register double-buffered.
+// Tiles are dealt to XCDs in contiguous ranges (blockIdx % 8 selects the range) so that neighbouring tiles, which
+// share their halo rows, share an L2.
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s).  Algorithmic work: cells * hs * 3456 * 2 FLOP
 // (+ hs*2 for the 1x1), i.e. 1 387.7 MFLOP per 28x28 frame at hs = 256.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;  // padded LDS row (floats): 144 B = 9 x 16 B -> conflict-free b128 fragment reads
-constexpr int NSTAGE = 9 * (SSLAM_C / BK);
+constexpr int NCHUNK = SSLAM_C / BK;
+constexpr int NSTAGE = 9 * NCHUNK;
 
-template <int WN>  // waves along N; hs = 64 * WN
+template <int WM, int WN, int NI, bool BDIRECT>
 __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__restrict__ feat, int n_rows, int G,
                                                                  const float *__restrict__ w1p,
                                                                  const float *__restrict__ b1,
                                                                  const float *__restrict__ w2,
-                                                                 const float *__restrict__ b2, float *__restrict__ sal) {
-    constexpr int WM = 8 / WN;
+                                                                 const float *__restrict__ b2, float *__restrict__ sal,
+                                                                 int n_tiles) {
+    static_assert(WM * WN == 8, "8 waves");
     constexpr int BM = 64 * WM;
-    constexpr int HS = 64 * WN;
-    constexpr int A_ITEMS = BM * 4 / 512;    // 8-float items per thread per stage
-    constexpr int B_ITEMS = HS * 8 / 512;    // float4 items per thread per stage
-    constexpr int STAGE_FLOATS = (BM + HS) * LDT;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    constexpr int HS = 32 * NI * WN;
+    constexpr int NSLAB = HS / 64;
+    constexpr int A_ITEMS = BM * 4 / 512;            // 8-float items per thread per stage
+    constexpr int B_ITEMS = BDIRECT ? 1 : HS * 8 / 512;   // float4 items per thread per stage
+    constexpr int STAGE_FLOATS = (BM + (BDIRECT ? 0 : HS)) * LDT;
+    constexpr int RED_FLOATS = NSLAB * BM;
+    constexpr int SMEM_FLOATS = 2 * STAGE_FLOATS > RED_FLOATS ? 2 * STAGE_FLOATS : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int cells = G * G;
-    const long long m0 = (long long)blockIdx.x * BM;
+    // XCD-aware tile mapping (bijective for any n_tiles): blocks b, b+8, b+16.. run on one XCD -> give them
+    // consecutive tiles
+    int tile;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+    }
+    const long long m0 = (long long)tile * BM;
 
     // per-thread A rows (fixed for the whole K loop)
     int a_row[A_ITEMS], a_kq[A_ITEMS], a_y[A_ITEMS], a_x[A_ITEMS];
@@ -64,7 +82,7 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
 #define LOAD_STAGE(S)                                                                                              \
     {                                                                                                              \
         const int s_ = (S);                                                                                        \
-        const int tap = s_ / (SSLAM_C / BK), chunk = s_ % (SSLAM_C / BK);                                          \
+        const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                            \
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;                                                              \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                      \
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;                                                          \
@@ -75,8 +93,10 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
             ra_lo[i] = make_float4(ok ? v0.x : 0.f, ok ? v0.y : 0.f, ok ? v0.z : 0.f, ok ? v0.w : 0.f);            \
             ra_hi[i] = make_float4(ok ? v1.x : 0.f, ok ? v1.y : 0.f, ok ? v1.z : 0.f, ok ? v1.w : 0.f);            \
         }                                                                                                          \
-        const float4 *wp = reinterpret_cast<const float4 *>(w1p + (long long)s_ * HS * BK);                        \
-        _Pragma("unroll") for (int i = 0; i < B_ITEMS; i++) rb[i] = wp[tid + 512 * i];                             \
+        if (!BDIRECT) {                                                                                            \
+            const float4 *wp = reinterpret_cast<const float4 *>(w1p + (long long)s_ * HS * BK);                    \
+            _Pragma("unroll") for (int i = 0; i < B_ITEMS; i++) rb[i] = wp[tid + 512 * i];                         \
+        }                                                                                                          \
     }
 #define STORE_STAGE(BUF)                                                                                           \
     {                                                                                                              \
@@ -89,22 +109,27 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
             *reinterpret_cast<float4 *>(d) = ev;                                                                   \
             *reinterpret_cast<float4 *>(d + 4) = od;                                                               \
         }                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < B_ITEMS; i++) {                                                      \
-            const int q = tid + 512 * i;                                                                           \
-            *reinterpret_cast<float4 *>(Bs_ + (q >> 3) * LDT + (q & 7) * 4) = rb[i];                               \
+        if (!BDIRECT) {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < B_ITEMS; i++) {                                                  \
+                const int q = tid + 512 * i; /* float4 index in [g][n][2] */                                      \
+                const int g_ = q / (HS * 2), n_ = (q >> 1) % HS;                                                   \
+                *reinterpret_cast<float4 *>(Bs_ + n_ * LDT + 8 * g_ + 4 * (q & 1)) = rb[i];                        \
+            }                                                                                                      \
         }                                                                                                          \
     }
 
-    // accumulators start from the conv bias: the fma chain is b1[n] + sum_k a_k * w_k in increasing k
-    f32x16 acc[2][2];
+    // accumulators start from the conv bias: the fma chain is b1[n] + sum_k a_k * w_k in canonical k order
+    f32x16 acc[2][NI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ni++) {
-        const float bv = b1[wn * 64 + ni * 32 + r];
+    for (int ni = 0; ni < NI; ni++) {
+        const float bv = b1[wn * 32 * NI + ni * 32 + r];
 #pragma unroll
         for (int mi = 0; mi < 2; mi++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
     }
+    // direct-B: lane's fragment of (stage s, k-group g, tile ni) = 16 B at (((s*4+g)*HS + n)*8 + 4h) floats
+    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 32 * NI + r) * 2 + h);
 
     LOAD_STAGE(0);
     STORE_STAGE(0);
@@ -112,52 +137,75 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
     for (int s = 0; s < NSTAGE; s++) {
         if (s + 1 < NSTAGE) LOAD_STAGE(s + 1);
         const float *As = smem + (s & 1) * STAGE_FLOATS + (wm * 64 + r) * LDT + 4 * h;
-        const float *Bs = smem + (s & 1) * STAGE_FLOATS + BM * LDT + (wn * 64 + r) * LDT + 4 * h;
+        const float *Bs = smem + (s & 1) * STAGE_FLOATS + BM * LDT + (wn * 32 * NI + r) * LDT + 4 * h;
+        f32x4 bq[BK / 8][NI];
+        if (BDIRECT) {
+#pragma unroll
+            for (int g = 0; g < BK / 8; g++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)(s * (BK / 8) + g) * HS + ni * 32) * 2];
+        }
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(As + 8 * g);
             const f32x4 a1 = *reinterpret_cast<const f32x4 *>(As + 32 * LDT + 8 * g);
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bs + 8 * g);
-            const f32x4 b1v = *reinterpret_cast<const f32x4 *>(Bs + 32 * LDT + 8 * g);
+            f32x4 b[NI];
 #pragma unroll
-            for (int st = 0; st < 4; st++) {
-                acc[0][0] = mfma32(a0[st], b0[st], acc[0][0]);
-                acc[0][1] = mfma32(a0[st], b1v[st], acc[0][1]);
-                acc[1][0] = mfma32(a1[st], b0[st], acc[1][0]);
-                acc[1][1] = mfma32(a1[st], b1v[st], acc[1][1]);
-            }
+            for (int ni = 0; ni < NI; ni++)
+                b[ni] = BDIRECT ? bq[g][ni] : *reinterpret_cast<const f32x4 *>(Bs + ni * 32 * LDT + 8 * g);
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) {
+                    acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
+                    acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
+                }
         }
         if (s + 1 < NSTAGE) STORE_STAGE((s + 1) & 1);
         __syncthreads();
     }
 
-    // epilogue: ReLU, 1x1 conv (canonical tree: in-lane pair, 32-lane butterfly, slabs in order), sigmoid
-    float *red = smem;  // [WN][BM]; every wave is past its last LDS read (barrier above)
-    const float w2a = w2[wn * 64 + r], w2b = w2[wn * 64 + 32 + r];
+    // epilogue: ReLU, 1x1 conv (canonical tree: in-lane pair per 64-column slab, 32-lane butterfly, slabs in
+    // order), sigmoid
+    float *red = smem;  // [NSLAB][BM]; every wave is past its last LDS read (barrier above)
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int sl = 0; sl < NI / 2; sl++) {
+        const int slab = wn * (NI / 2) + sl;
+        const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const float h0 = acc[mi][0][e] > 0.0f ? acc[mi][0][e] : 0.0f;
-            const float h1 = acc[mi][1][e] > 0.0f ? acc[mi][1][e] : 0.0f;
-            const float q = h0 * w2a + h1 * w2b;
-            const float t = bfly32(q);
-            if (r == 0) red[wn * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
-        }
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
+                const float h1 = acc[mi][2 * sl + 1][e] > 0.0f ? acc[mi][2 * sl + 1][e] : 0.0f;
+                const float q = h0 * w2a + h1 * w2b;
+                const float t = bfly32(q);
+                if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+            }
+    }
     __syncthreads();
     for (int t = tid; t < BM; t += 512) {
         const long long m = m0 + t;
         if (m < n_rows) {
             float logit = b2[0];
 #pragma unroll
-            for (int s = 0; s < WN; s++) logit = logit + red[s * BM + t];
+            for (int s = 0; s < NSLAB; s++) logit = logit + red[s * BM + t];
             sal[m] = sslam_sigmoid(logit);
         }
     }
 }
-
 #undef LOAD_STAGE
 #undef STORE_STAGE
+
+template <int WM, int WN, int NI, bool BD>
+void launch(const float *feat, long long rows, int G, const float *w1p, const float *b1, const float *w2, const float *b2,
+            float *sal, hipStream_t st) {
+    constexpr int BM = 64 * WM;
+    const int n_tiles = (int)((rows + BM - 1) / BM);
+    hipLaunchKernelGGL((selector_saliency_kernel<WM, WN, NI, BD>), dim3(n_tiles), dim3(512), 0, st, feat, (int)rows, G, w1p, b1,
+                       w2, b2, sal, n_tiles);
+}
+
 }  // namespace
 
 extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
@@ -167,14 +215,20 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     const long long rows = (long long)n_frames * G * G;
     if (rows > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // tuning knob; measured on MI355X (613 frames, G=28): 0: 7.16 ms, 1: 7.06, 2: 6.67 (default), 3: 7.97
+    static const int variant = getenv("SSLAM_CONV_VARIANT") ? atoi(getenv("SSLAM_CONV_VARIANT")) : 2;
     if (hs == 256) {
-        const unsigned grid = (unsigned)((rows + 127) / 128);
-        hipLaunchKernelGGL(selector_saliency_kernel<4>, dim3(grid), dim3(512), 0, st, feat, (int)rows, G, w1_packed, b1,
-                           w2, b2, sal);
+        switch (variant) {
+            case 0: launch<2, 4, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
+            case 1: launch<4, 2, 4, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
+            case 3: launch<4, 2, 4, true>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
+            default: launch<2, 4, 2, true>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
+        }
     } else if (hs == 128) {
-        const unsigned grid = (unsigned)((rows + 255) / 256);
-        hipLaunchKernelGGL(selector_saliency_kernel<2>, dim3(grid), dim3(512), 0, st, feat, (int)rows, G, w1_packed, b1,
-                           w2, b2, sal);
+        if (variant >= 2)
+            launch<4, 2, 2, true>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
+        else
+            launch<4, 2, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
     } else {
         return SSLAM_E_UNSUPPORTED;
     }
@@ -182,15 +236,15 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     return SSLAM_OK;
 }
 
-// w (hs, 384, 3, 3) -> [stage = tap*12 + chunk][n][32 floats in KP8 order]
+// w (hs, 384, 3, 3) -> [stage = chunk*9 + tap][k-group g (4)][n][8 floats in KP8 order] (MFMA B-fragment order)
 extern "C" int sslam_pack_conv3x3_host(const float *w, int hs, float *out) {
     if (!w || !out || hs <= 0) return SSLAM_E_INVALID;
-    for (int tap = 0; tap < 9; tap++)
-        for (int chunk = 0; chunk < SSLAM_C / BK; chunk++)
+    for (int chunk = 0; chunk < NCHUNK; chunk++)
+        for (int tap = 0; tap < 9; tap++)
             for (int n = 0; n < hs; n++)
                 for (int k = 0; k < BK; k++) {
-                    const int c = chunk * BK + k;
-                    out[(((long long)(tap * (SSLAM_C / BK) + chunk) * hs + n) * BK) + kp8(k)] =
+                    const int c = chunk * BK + k, stage = chunk * 9 + tap;
+                    out[((((long long)stage * (BK / 8) + k / 8) * hs + n) * 8) + kp8(k % 8)] =
                         w[((long long)n * SSLAM_C + c) * 9 + tap];
                 }
     return SSLAM_OK;

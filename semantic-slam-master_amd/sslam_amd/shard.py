@@ -7,7 +7,8 @@ are per frame), so the only data that crosses GPUs is what the matcher needs at 
 
   1. halo - each rank sends the descriptors / scores / intensities of its FIRST `spacing` frames to rank-1
      (point-to-point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link, never bandwidth-bound);
-  2. results - per-pair match counts are all-gathered, then the padded match records are gathered to rank 0.
+  2. results - per-rank pair counts are all-gathered, then the padded match records are all-gathered and kept by
+     rank 0 (all_gather rather than gather: fixed-size, the most widely exercised RCCL collective).
 
 No all-reduce, no weight traffic after the optional initial broadcast of the packed weights.
 """
@@ -86,7 +87,8 @@ class ShardedSequenceRunner:
 
     # ---------------------------------------------------------------------------------------------- gather
     def _gather(self, m: dict) -> dict:
-        """All ranks learn every rank's pair count; rank 0 receives all (padded) match records in frame order."""
+        """All ranks learn every rank's pair count, then the padded match records are all-gathered (one fixed-size
+        collective per array; <= 10 KB per pair) and rank 0 keeps them, concatenated in frame order."""
         w, r = self.world, self.rank
         dev = m["match_count"].device
         npairs = torch.tensor([m["match_count"].shape[0]], dtype=torch.int64, device=dev)
@@ -105,8 +107,8 @@ class ShardedSequenceRunner:
                 pad(m["matches"], (K, 2), torch.int64)]
         res = {}
         for name, t in zip(("all_match_count", "all_quality", "all_matches"), send):
-            bufs = [torch.empty_like(t) for _ in range(w)] if r == 0 else None
-            dist.gather(t, bufs, dst=0, group=self.group)
+            bufs = [torch.empty_like(t) for _ in range(w)]
+            dist.all_gather(bufs, t, group=self.group)
             if r == 0:
                 res[name] = torch.cat([b[:c] for b, c in zip(bufs, counts)])
         res["pairs_per_rank"] = counts

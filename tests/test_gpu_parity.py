@@ -106,7 +106,7 @@ def test_selector_matches_reference_golden(T, hip):
     feat = ora.bn_tokens(synth.tokens(1, 28))[0].reshape(1, 28, 28, 384)
     w1p, b1, w2, b2, hs = _packed_selector(T, hip, sd)
     sal = hip.selector_saliency(dev(T, feat), w1p, b1, w2, b2, hs).cpu().numpy()[0]
-    assert np.abs(sal - g["g28_saliency"]).max() < 2e-6
+    assert np.abs(sal - g["g28_saliency"]).max() < 5e-6
 
 
 # ---------------------------------------------------------------------------------------------------- A4 / A5
@@ -350,7 +350,7 @@ def test_dropin_modules_on_gpu(T, hip):
             pix = bb.patch_to_pixel(kp)
             assert f.shape == (1, 28, 28, 384) and sal.shape == (1, 28, 28, 1) and desc.shape == (1, 500, 128)
             assert np.array_equal(kp[0].cpu().numpy(), g[f"f{i}_kp"])
-            assert np.abs(sc[0].cpu().numpy() - g[f"f{i}_scores"]).max() < 2e-6
+            assert np.abs(sc[0].cpu().numpy() - g[f"f{i}_scores"]).max() < 5e-6
             assert np.abs(desc[0, ::5].cpu().numpy() - g[f"f{i}_desc_sub"]).max() < 1e-5
             assert np.array_equal(pix[0].cpu().numpy(), g[f"f{i}_kp"] * 16 + 8)
     assert hip.launch_count() >= before + 3 * 5, "the HIP kernels must have served these calls"

@@ -51,12 +51,12 @@ def test_host_side_packing_and_tables():
     from sslam_amd import lib
     from oracle import ora
     w = synth.selector_state(0)["conv.0.weight"]
-    p = lib.pack_conv3x3(w).reshape(9, 12, 256, 32)
-    # stage (tap, chunk) holds [n][32 k] with k permuted (0,2,4,6,1,3,5,7) inside groups of 8
+    p = lib.pack_conv3x3(w).reshape(12, 9, 4, 256, 8)
+    # stage (chunk, tap) holds [k-group][n][8 k] with k permuted (0,2,4,6,1,3,5,7): the MFMA B-fragment order
     perm = np.array([0, 2, 4, 6, 1, 3, 5, 7])
     for tap, chunk, n in [(0, 0, 0), (4, 7, 100), (8, 11, 255)]:
-        want = w[n, chunk * 32:(chunk + 1) * 32, tap // 3, tap % 3].reshape(4, 8)[:, perm].reshape(-1)
-        assert np.array_equal(p[tap, chunk, n], want)
+        want = w[n, chunk * 32:(chunk + 1) * 32, tap // 3, tap % 3].reshape(4, 8)[:, perm]
+        assert np.array_equal(p[chunk, tap, :, n], want)
     ws = ora.refiner_weight_list(synth.refiner_state(0), 2)
     packed = lib.pack_refiner(ws, 2)
     lay = lib.refiner_layout(2)
