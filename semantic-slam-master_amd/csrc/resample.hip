@@ -75,6 +75,98 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
     }
 }
 
+// Fast path (horizontal taps <= 7, i.e. bilinear down to 1/3 or bicubic down to 2/3 of the input width):
+//  - a thread owns ONE output column for the whole tile, so its bounds / coefficients live in registers;
+//  - the <= 21 source bytes of a pixel are fetched as six aligned dwords and re-aligned with v_alignbyte
+//    (byte loads made the first version of this kernel TA-instruction bound at 1.36 TB/s);
+//  - the uint8 intermediate row is kept packed (R | G<<8 | B<<16) so the vertical pass reads one dword per tap.
+__global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
+                                                               const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
+                                                               const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
+                                                               float *__restrict__ out) {
+    __shared__ unsigned tmp[MAXR][TX];
+    __shared__ float lut[3][256];
+    const int tid = threadIdx.x;
+    const long long f = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int ty1 = min(y0 + TY, size) - 1;
+    const int rmin = bv[2 * y0], rmax = bv[2 * ty1] + bv[2 * ty1 + 1];   // input rows [rmin, rmax)
+    const int nrows = rmax - rmin;
+    const long long total_bytes = (long long)gridDim.z * h * w * 3;
+    const long long frame0 = f * h * w * 3;
+    {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; c++) lut[c][tid] = ((float)tid / 255.0f - mean[c]) / sd[c];
+    }
+    const int xx = tid & (TX - 1), q = tid >> 6;                           // q = 0..3
+    const int ox = min(x0 + xx, size - 1);
+    {
+        const int xmin = bh[2 * ox], xn = bh[2 * ox + 1];
+        int kh[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++) kh[t] = t < xn ? ch[(long long)ox * ksh + t] : 0;
+        for (int rr = q; rr < nrows; rr += 4) {
+            const long long b0 = frame0 + ((long long)(rmin + rr) * w + xmin) * 3;
+            const long long a0 = b0 & ~3LL;
+            const int sh = (int)(b0 & 3);
+            unsigned wds[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const long long a = a0 + 4 * j;
+                unsigned v = 0;
+                if (a + 4 <= total_bytes) {
+                    v = *reinterpret_cast<const unsigned *>(img + a);
+                } else {
+                    for (int k = 0; k < 4; k++)
+                        if (a + k < total_bytes) v |= (unsigned)img[a + k] << (8 * k);
+                }
+                wds[j] = v;
+            }
+            unsigned al[6];                                                  // bytes b0.. in order
+#pragma unroll
+            for (int j = 0; j < 5; j++) al[j] = __builtin_amdgcn_alignbyte(wds[j + 1], wds[j], sh);
+            al[5] = wds[5] >> (8 * sh);
+            int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const int o = 3 * t;
+                const int r8 = (al[o >> 2] >> (8 * (o & 3))) & 255;
+                const int g8 = (al[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255;
+                const int b8 = (al[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255;
+                s0 += r8 * kh[t];
+                s1 += g8 * kh[t];
+                s2 += b8 * kh[t];
+            }
+            tmp[rr][xx] = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16);
+        }
+    }
+    __syncthreads();
+    const long long plane = (long long)size * size;
+    if (x0 + xx < size) {
+#pragma unroll
+        for (int j = 0; j < TY / 4; j++) {
+            const int oy = y0 + q * (TY / 4) + j;
+            if (oy < size) {
+                const int ymin = bv[2 * oy] - rmin, yn = bv[2 * oy + 1];
+                const int *k = cv + (long long)oy * ksv;
+                int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+                for (int t = 0; t < yn; t++) {
+                    const unsigned p = tmp[ymin + t][xx];
+                    const int kk = k[t];
+                    s0 += (int)(p & 255) * kk;
+                    s1 += (int)((p >> 8) & 255) * kk;
+                    s2 += (int)((p >> 16) & 255) * kk;
+                }
+                float *o = out + f * 3 * plane + (long long)oy * size + (x0 + xx);
+                o[0] = lut[0][clip8(s0)];
+                o[plane] = lut[1][clip8(s1)];
+                o[2 * plane] = lut[2][clip8(s2)];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void intensity_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
                                                          const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
                                                          const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
@@ -173,8 +265,13 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
     // input rows one output tile can need: TY output rows span TY*scale input rows plus the filter support
     if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
     if (n > 65535) return SSLAM_E_UNSUPPORTED;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((size + TX - 1) / TX, (size + TY - 1) / TY, n), dim3(256), 0,
-                       (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+    const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, n);
+    if (ksize_h <= 7 && !((uintptr_t)img & 3))
+        hipLaunchKernelGGL(preprocess_fast_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h,
+                           ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+    else
+        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h,
+                           ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }
