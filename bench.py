@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--workload", default="fr1_desk_613", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
+    ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +193,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # additional leg (N = 1): the same pass with the tokens computed on the GPU by the HIP ViT-S/16 (A1, random weights
+    # of the DINOv3 architecture - pretrained weights are a remote fetch): images -> A0 -> A1 -> A2 .. M1
+    vit_leg = None
+    if world == 1 and not args.no_vit:
+        from sslam_amd.vit import DinoV3ViT
+        torch.manual_seed(0)
+        pipe_v = SequencePipeline(cfg, ssd, rsd, device=dev, vit=DinoV3ViT().to(dev).eval())
+        for _ in range(max(1, args.warmup)):
+            pipe_v.run(imgs)
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        nv = max(1, min(args.steps, 3))
+        for _ in range(nv):
+            ov = pipe_v.run(imgs)
+        torch.cuda.synchronize()
+        dtv = (time.perf_counter() - tv) / nv
+        cells_ = grid * grid
+        t_ = cells_ + 5
+        vit_flop = 12 * (t_ * 384 * 1152 * 2 + 2 * 6 * t_ * t_ * 64 * 2 + t_ * 384 * 384 * 2 + 2 * t_ * 384 * 1536 * 2) + cells_ * 768 * 384 * 2
+        vit_leg = {"value": round(n / dtv, 2), "unit": "frames/s", "ms_per_step": round(dtv * 1e3, 3),
+                   "what": "images -> A0 -> HIP ViT-S/16 (A1, bf16 MFMA, random DINOv3-architecture weights) -> A2..A9 -> M1",
+                   "vit_gflop_per_frame": round(vit_flop / 1e9, 2), "matches_per_pair": round(float(ov["match_count"].float().mean().item()), 1)}
+        del pipe_v, ov
+
     if rank == 0:
         stage_ms = {k: round(float(np.mean([a.elapsed_time(b) for a, b in v])), 4) for k, v in ev.items()}
         cells = grid * grid
@@ -229,6 +254,8 @@ def main():
             "parity": {"frames_checked_vs_oracle": nchk, "bit_exact": ok},
             "matches_per_pair": round(float(out["match_count"].float().mean().item()), 1),
         }
+        if world == 1 and not args.no_vit:
+            res["with_vit"] = vit_leg
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
         print(json.dumps(res))

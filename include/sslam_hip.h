@@ -144,6 +144,37 @@ int sslam_match_finalize(const int32_t *nn12, const float *s12, const int32_t *n
                          float min_saliency, float min_sim, float min_intensity, int64_t *matches, float *quality,
                          int32_t *count, void *stream);
 
+/* ---- A1: DINOv3 ViT-S/16 forward.  Replaces the third-party call
+ * `self.dino.forward_features(images)` at dino_backbone.py:85 (timm model "vit_small_patch16_dinov3"): 16x16 patch
+ * embedding, [CLS] + 4 register tokens, 12 pre-LN blocks (6 heads x 64, q/v/proj bias, axial RoPE theta 100 on the
+ * patch tokens, LayerScale, MLP 1536 GELU), final LayerNorm.  bf16 MFMA operands, fp32 accumulation / LayerNorm /
+ * softmax / residual stream: tolerance-level parity with an fp32 evaluation (not bit-exact).
+ * All pointers are DEVICE pointers; vectors fp32; matrices bf16, nn.Linear (n_out, k_in) re-ordered into MFMA
+ * B-fragment order [n_out/32][k_in/16][2][32][8] (element (n, k) -> [n/32][k/16][(k%16)/8][n%32][k%8]).
+ * wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), bqkv likewise with ZEROS for the k rows (no key bias);
+ * patch_w = Conv2d weight reshaped (384, 768); prefix = [cls; reg0..3] (5, 384); rope_cos / rope_sin (G*G, 64) fp32.
+ * images_chw (n, 3, size, size) fp32 (the output of sslam_preprocess_u8) -> tokens_out (n, 5 + (size/16)^2, 384). */
+typedef struct {
+    const float *ln1_g, *ln1_b;
+    const void *wqkv;
+    const float *bqkv;
+    const void *wo;
+    const float *bo, *ls1, *ln2_g, *ln2_b;
+    const void *wup;
+    const float *bup;
+    const void *wdown;
+    const float *bdown, *ls2;
+} sslam_vit_layer_t;
+typedef struct {
+    const void *patch_w;
+    const float *patch_b, *prefix;
+    sslam_vit_layer_t layer[12];
+    const float *norm_g, *norm_b, *rope_cos, *rope_sin;
+} sslam_vit_weights_t;
+long long sslam_vit_workspace_bytes(int n_frames, int size);
+int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
+                      void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,10 +55,27 @@ class DinoBackbone(nn.Module):
         return not next(self.dino.parameters()).requires_grad
 
     # -------------------------------------------------------------------------------------------- forward
+    def _hip_vit(self):
+        """HIP execution of the in-repo ViT definition (bf16 MFMA); rebuilt when the ViT's parameters change."""
+        from sslam_amd.vit import DinoV3ViT
+        from sslam_amd.vit_hip import HipViT
+        if not isinstance(self.dino, DinoV3ViT):
+            return None
+        ps = list(self.dino.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_hip_vit_obj", None) is None or self._hip_vit_key != key:
+            self._hip_vit_obj, self._hip_vit_key = HipViT(self.dino, ps[0].device), key
+        return self._hip_vit_obj
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         """(B, 3, H, W) -> (B, grid_h, grid_w, embed_dim) patch features (dino_backbone.py:70-108)."""
-        with torch.set_grad_enabled(self.training and not self._is_frozen()):
-            features = self.dino.forward_features(images)
+        grad = self.training and not self._is_frozen()
+        hv = self._hip_vit() if (images.is_cuda and not (grad and torch.is_grad_enabled())) else None
+        if hv is not None:
+            features = hv.forward_features(images)          # HIP ViT-S/16 (tolerance-level parity, bf16 operands)
+        else:
+            with torch.set_grad_enabled(grad):
+                features = self.dino.forward_features(images)
         return self.tokens_to_features(features)
 
     def tokens_to_features(self, features: torch.Tensor) -> torch.Tensor:

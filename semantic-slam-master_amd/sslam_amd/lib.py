@@ -27,6 +27,16 @@ class SslamHipError(RuntimeError):
     pass
 
 
+class VitLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ls1", "ln2_g", "ln2_b", "wup", "bup",
+                                          "wdown", "bdown", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p), ("layer", VitLayer * 12),
+                ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+
+
 class RefinerLayout(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("total", C.c_longlong), ("in_w", C.c_longlong), ("in_b", C.c_longlong),
                 ("blk", (C.c_longlong * 8) * 8), ("out_w", C.c_longlong), ("out_b", C.c_longlong)]
@@ -49,6 +59,7 @@ EXPORTS = [
     "sslam_resample_table_host", "sslam_preprocess_u8", "sslam_bn_tokens", "sslam_selector_saliency",
     "sslam_select_keypoints", "sslam_gather", "sslam_refiner_layout", "sslam_refiner_pack_host", "sslam_refine",
     "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
+    "sslam_vit_workspace_bytes", "sslam_vit_forward",
 ]
 
 
@@ -78,6 +89,9 @@ def lib():
         L.sslam_keypoint_intensity.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, i, p, p]
         L.sslam_sim_argmax.argtypes = [p, ll, i, p, ll, i, i, p, p, p, p, p, p]
         L.sslam_match_finalize.argtypes = [p, p, p, i, i, i, p, ll, p, ll, p, p, f, f, f, f, f, p, p, p, p]
+        L.sslam_vit_workspace_bytes.restype = C.c_longlong
+        L.sslam_vit_workspace_bytes.argtypes = [i, i]
+        L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
         _lib = L
     return _lib
 
@@ -251,3 +265,20 @@ def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in
                                       f(w_desc), f(w_sal), f(t_sal), f(t_sim), f(t_int), _dp(matches), _dp(quality),
                                       _dp(count), _stream()), "match_finalize")
     return matches, quality, count
+
+
+def vit_workspace_bytes(n_frames: int, size: int) -> int:
+    b = int(lib().sslam_vit_workspace_bytes(n_frames, size))
+    if b < 0:
+        _check(b, "vit_workspace_bytes")
+    return b
+
+
+def vit_forward(images_chw, weights: VitWeights, workspace, out=None):
+    n, _, size, _ = images_chw.shape
+    t = 5 + (size // 16) ** 2
+    if out is None:
+        out = torch.empty((n, t, C_FEAT), dtype=torch.float32, device=images_chw.device)
+    _check(lib().sslam_vit_forward(_dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(),
+                                   _dp(out), _stream()), "vit_forward")
+    return out

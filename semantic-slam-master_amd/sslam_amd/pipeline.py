@@ -107,7 +107,8 @@ class ResampleTables:
 
 class SequencePipeline:
     def __init__(self, cfg: ExtractorConfig, selector_state: dict, refiner_state: dict, bn_state: dict | None = None,
-                 device="cuda"):
+                 device="cuda", vit=None):
+        """vit: optional sslam_amd.vit.DinoV3ViT - enables run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ..."""
         self.cfg = cfg
         self.device = torch.device(device)
         lib.lib()   # fail loudly if the HIP library is not built
@@ -121,6 +122,10 @@ class SequencePipeline:
         self.bn_mean = torch.as_tensor(_np(bn.get("running_mean", np.zeros(c))), **f32).contiguous()
         self.bn_var = torch.as_tensor(_np(bn.get("running_var", np.ones(c))), **f32).contiguous()
         self.tables = ResampleTables(self.device)
+        self.vit_hip = None
+        if vit is not None:
+            from .vit_hip import HipViT
+            self.vit_hip = HipViT(vit, self.device)
 
     # ---------------------------------------------------------------------------------------------- stages
     def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
@@ -128,6 +133,21 @@ class SequencePipeline:
         n, h, w, _ = images_u8.shape
         th, tv = self.tables.get(h, w, self.cfg.input_size, False)
         return lib.preprocess_u8(images_u8, self.cfg.input_size, th, tv)
+
+    def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int = 64) -> torch.Tensor:
+        """A0 + A1: (N, H, W, 3) uint8 -> (N, 5 + G*G, 384) fp32 tokens via the HIP ViT, `vit_chunk` frames at a time
+        (the ViT workspace of a chunk, ~7 MB per frame, then stays within the 256 MB Infinity Cache)."""
+        if self.vit_hip is None:
+            raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
+        out = torch.empty((images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT), dtype=torch.float32, device=self.device)
+        for a in range(0, images_u8.shape[0], vit_chunk):
+            b = min(a + vit_chunk, images_u8.shape[0])
+            x = self.preprocess(images_u8[a:b])
+            need = lib.vit_workspace_bytes(b - a, self.cfg.input_size)
+            if self.vit_hip._ws is None or self.vit_hip._ws.numel() < need:
+                self.vit_hip._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.vit_hip.forward_features(x, out=out[a:b])
+        return out
 
     def features(self, tokens: torch.Tensor) -> torch.Tensor:
         """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features."""
@@ -171,9 +191,13 @@ class SequencePipeline:
                                         cfg.min_descriptor_sim, cfg.min_intensity)
         return dict(matches=mt, quality=q, match_count=cnt, nn12=nn12, nn21=nn21, sim=s12)
 
-    def run(self, images_u8: torch.Tensor | None, tokens: torch.Tensor, with_preprocess: bool = False) -> dict:
-        """One pass of the hot path over a frame sequence: extract every frame once, match (i, i+spacing)."""
+    def run(self, images_u8: torch.Tensor | None, tokens: torch.Tensor | None = None, with_preprocess: bool = False) -> dict:
+        """One pass of the hot path over a frame sequence: extract every frame once, match (i, i+spacing).
+        tokens=None: compute them from the images with the HIP ViT (A0 + A1)."""
         cfg = self.cfg
+        if tokens is None:
+            tokens = self.tokens_from_images(images_u8)
+            with_preprocess = False
         n = tokens.shape[0]
         parts = []
         vit_in = None

@@ -1,0 +1,65 @@
+"""HIP execution of the DINOv3 ViT-S/16 forward (sslam_vit_forward, csrc/vit.hip) for a `sslam_amd.vit.DinoV3ViT`
+module: packs its Parameters into device buffers (matrices bf16, vectors fp32), builds the RoPE tables, owns the
+workspace.  PyTorch is plumbing; no torch op takes part in the forward."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib
+from .vit import DinoV3ViT
+
+
+class HipViT:
+    def __init__(self, vit: DinoV3ViT, device="cuda"):
+        if (vit.embed_dim, vit.heads, vit.patch, vit.n_register, len(vit.blocks)) != (384, 6, 16, 4, 12):
+            raise lib.SslamHipError("the HIP ViT is built for ViT-S/16 with 4 register tokens (384 / 6 heads / 12 layers)")
+        if vit.blocks[0].up_proj.out_features != 1536:
+            raise lib.SslamHipError("MLP width must be 1536")
+        self.vit, self.device = vit, torch.device(device)
+        self._keep = []
+        self._rope = {}
+        self._ws = None
+        self.w = lib.VitWeights()
+        bf, f32 = self._frag, self._f32
+        self.w.patch_w = bf(vit.patch_embed.weight.reshape(384, 768))
+        self.w.patch_b = f32(vit.patch_embed.bias)
+        self.w.prefix = f32(torch.cat([vit.cls_token[0], vit.register_tokens[0]], dim=0))
+        for i, b in enumerate(vit.blocks):
+            ly = self.w.layer[i]
+            ly.ln1_g, ly.ln1_b = f32(b.norm1.weight), f32(b.norm1.bias)
+            ly.wqkv = bf(torch.cat([b.q_proj.weight, b.k_proj.weight, b.v_proj.weight], dim=0))
+            ly.bqkv = f32(torch.cat([b.q_proj.bias, torch.zeros_like(b.q_proj.bias), b.v_proj.bias]))
+            ly.wo, ly.bo, ly.ls1 = bf(b.o_proj.weight), f32(b.o_proj.bias), f32(b.ls1)
+            ly.ln2_g, ly.ln2_b = f32(b.norm2.weight), f32(b.norm2.bias)
+            ly.wup, ly.bup = bf(b.up_proj.weight), f32(b.up_proj.bias)
+            ly.wdown, ly.bdown, ly.ls2 = bf(b.down_proj.weight), f32(b.down_proj.bias), f32(b.ls2)
+        self.w.norm_g, self.w.norm_b = f32(vit.norm.weight), f32(vit.norm.bias)
+
+    def _hold(self, t):
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _frag(self, w):
+        """(N, K) nn.Linear weight -> bf16 in MFMA B-fragment order [N/32][K/16][2][32][8] (csrc/vit.hip gemm_ares_kernel)."""
+        n, k = w.shape
+        t = w.detach().to(self.device, torch.bfloat16).reshape(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4)
+        return self._hold(t.contiguous())
+
+    def _f32(self, t):
+        return self._hold(t.detach().to(self.device, torch.float32).contiguous())
+
+    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed)."""
+        n, _, s, s2 = images.shape
+        assert s == s2 and s % 16 == 0 and images.is_cuda
+        g = s // 16
+        if g not in self._rope:
+            cos, sin = self.vit.rope_tables(g, g, self.device)
+            self._rope[g] = (cos.float().contiguous(), sin.float().contiguous())
+        self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
+        need = lib.vit_workspace_bytes(n, s)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return lib.vit_forward(images.detach().float().contiguous(), self.w, self._ws, out=out)

@@ -362,3 +362,32 @@ def test_dropin_modules_on_gpu(T, hip):
     rm, rv = bb.feature_norm.running_mean.cpu().numpy(), bb.feature_norm.running_var.cpu().numpy()
     want = ora.bn_tokens(toks[:2], 5, 2, run_mean=rm, run_var=rv, train=False)[0]
     assert_bits(f.cpu().numpy().reshape(2, 784, 384), want, "eval-mode BN with the tracked running stats")
+
+
+def test_pipeline_with_hip_vit_end_to_end(T, hip):
+    """images -> A0 -> HIP ViT (A1) -> A2..A9 -> M1 in one call; and the drop-in DinoBackbone uses the HIP ViT too."""
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    from sslam_amd.vit import DinoV3ViT
+    T.manual_seed(3)
+    vit = DinoV3ViT().cuda().eval()
+    imgs = T.from_numpy(synth.image_sequence(5)).cuda()
+    pipe = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda", vit=vit)
+    out = pipe.run(imgs)
+    assert out["descriptors"].shape == (5, 500, 128) and out["match_count"].shape == (4,)
+    assert int(out["status"].sum()) == 0
+    # the stages after the ViT are bit-exact given its tokens
+    tok = pipe.tokens_from_images(imgs).cpu().numpy()
+    feat = ora.bn_tokens(tok)[0].reshape(5, 28, 28, 384)
+    _, _, oidx, _ = ora.select_keypoints(ora.selector_saliency(feat, synth.selector_state(0)), 500)
+    assert np.array_equal(out["idx"].cpu().numpy(), oidx)
+    # tokens agree with the fp32 torch evaluation of the same weights at bf16-operand tolerance
+    with T.no_grad():
+        want = vit.forward_features(pipe.preprocess(imgs))
+    rel = float((T.from_numpy(tok).cuda() - want).norm() / want.norm())
+    assert rel < 2.5e-2, rel
+    bb = DinoBackbone(input_size=448, dino=vit).cuda()
+    before = hip.launch_count()
+    with T.no_grad():
+        f = bb(pipe.preprocess(imgs[:2]))
+    assert f.shape == (2, 28, 28, 384) and hip.launch_count() >= before + 80      # 12 layers x 7 launches

@@ -1,0 +1,62 @@
+"""A1: the in-repo DINOv3 ViT-S/16 definition against the same architecture family in `transformers`
+(DINOv3ViTModel built FROM CONFIG with random weights - no download), and the HIP forward against that definition.
+Parity with the reference's *pretrained* timm weights cannot be pinned offline (remote fetch): "parity unpinned" there."""
+import numpy as np
+import pytest
+import torch
+
+
+def _hf_pair(seed=0):
+    from transformers import DINOv3ViTConfig, DINOv3ViTModel
+    from sslam_amd.vit import DinoV3ViT
+    torch.manual_seed(seed)
+    hf = DINOv3ViTModel(DINOv3ViTConfig(num_register_tokens=4)).eval()
+    with torch.no_grad():      # make LayerScale / biases / norms non-trivial so that every term is exercised
+        for n, p in hf.named_parameters():
+            if "lambda1" in n:
+                p.copy_(0.5 + torch.rand_like(p))
+            elif n.endswith("bias") or "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            elif "cls_token" in n or "register_tokens" in n:
+                p.copy_(0.5 * torch.randn_like(p))
+            else:
+                p.mul_(3.0)
+    mine = DinoV3ViT().eval()
+    mine.load_hf_state_dict(hf.state_dict())
+    return hf, mine
+
+
+def test_vit_definition_matches_transformers_dinov3():
+    hf, mine = _hf_pair()
+    x = torch.randn(2, 3, 64, 96)             # non-square grid (4 x 6 patches): RoPE axes must not be swapped
+    with torch.no_grad():
+        want = hf(pixel_values=x).last_hidden_state
+        got = mine.forward_features(x)
+    assert got.shape == want.shape == (2, 1 + 4 + 24, 384)
+    assert float((got - want).abs().max()) < 2e-4
+    assert mine.embed_dim == 384
+    assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for n, p in hf.named_parameters() if "mask_token" not in n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,frames", [(448, 2), (224, 3), (640, 1)])
+def test_hip_vit_matches_fp32_definition(size, frames):
+    from sslam_amd import lib
+    from sslam_amd.vit_hip import HipViT
+    _, mine = _hf_pair(1)
+    mine = mine.cuda()
+    torch.manual_seed(size)
+    x = torch.randn(frames, 3, size, size, device="cuda")
+    before = lib.launch_count()
+    with torch.no_grad():
+        want = mine.forward_features(x)                 # fp32 torch ops on the same weights
+        got = HipViT(mine).forward_features(x)
+    assert lib.launch_count() > before
+    assert got.shape == want.shape
+    err = (got - want).float()
+    rel = float(err.norm() / want.norm())
+    assert rel < 2.5e-2, rel                            # bf16 operands, fp32 accumulation: ~1e-2 after 12 layers
+    assert float(err.abs().max()) < 0.35
+    # token-wise cosine similarity: every token, not just the average
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
+    assert float(cos.min()) > 0.995

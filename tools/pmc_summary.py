@@ -12,15 +12,18 @@ import os
 import sys
 
 KEEP = ("selector_saliency", "gather_refine", "sim_argmax", "bn_tokens", "preprocess_kernel", "select_keypoints",
-        "intensity_kernel", "match_finalize", "gather_kernel", "vit_")
+        "intensity_kernel", "match_finalize", "gather_kernel", "gemm_ares_kernel", "gemm_bf16_kernel", "attn_kernel", "ln_rows_kernel",
+        "mlp_fused_kernel", "im2patch")
 
 
 def short(name):
     for k in KEEP:
         if k in name:
             i = name.find(k)
-            j = name.find("(", i)
-            return name[i:j if j > 0 else None]
+            j = name.find("(bool", i)
+            if j < 0:
+                j = name.find("(", i + len(k) + 40) if "<" in name[i:i + len(k) + 2] else name.find("(", i)
+            return name[i:j if j > 0 else None].replace("(anonymous namespace)::", "")
     return None
 
 
