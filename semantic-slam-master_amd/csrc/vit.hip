@@ -358,7 +358,7 @@ struct EpiQKV {
     __device__ __forceinline__ void slice(f32x16 (&acc)[MT], int row0, int col0, int r, int h, int M) const {
         const int which = col0 / VD, head = (col0 % VD) / VHD, d = (col0 % VHD) + r;
         bf16 *dst = which == 0 ? q : (which == 1 ? k : v);
-        const float b = bias[col0 + r], sc = which == 0 ? 0.125f : 1.0f;
+        const float b = bias[col0 + r], sc = which == 0 ? 0.125f * LOG2E : 1.0f;   // q: 1/sqrt(64) and the exp2 domain
         const int f0 = row0 / T, t0 = row0 - f0 * T;      // one division per tile: a tile spans <= 2 frames (T > 128)
         int loff = 4 * h * VHD + d;
         asm volatile("" : "+v"(loff));
@@ -392,8 +392,8 @@ struct EpiQKV {
                         x1 = y1;
                     }
                     if (which == 0) {
-                        x0 *= 0.125f;
-                        x1 *= 0.125f;
+                        x0 *= 0.125f * LOG2E;
+                        x1 *= 0.125f * LOG2E;
                     }
                     bf16 *p = dst + (((long long)f * VH + head) * T + t) * VHD;
                     p[r] = (bf16)x0;
@@ -472,9 +472,8 @@ __global__ __launch_bounds__(256) void prefix_rows_kernel(const float *__restric
 // --------------------------------------------------------------------------------------------- attention
 constexpr int AQ = 128, AKT = 64, KLD = 72, VLD = 76;
 
-// RoPE (q' = q*cos + rotate_half(q)*sin on the patch tokens) is applied here, on load: the partner of element d is
-// d +- 32, which for a query fragment is the fragment two k-steps away in the SAME lane, and for a staged key row is
-// the 16-B chunk four chunks away (one thread stages both).  The tables satisfy cos[d] == cos[d+32] (angles tiled twice).
+// RoPE (q' = q*cos + rotate_half(q)*sin on the patch tokens): the partner of element d is d +- 32.  The tables satisfy
+// cos[d] == cos[d+32] (angles tiled twice), so one (cos, sin) octet serves both halves.
 __device__ __forceinline__ void rope8(u32x4 &lo, u32x4 &hi, const float4 &c0, const float4 &c1, const float4 &s0, const float4 &s1) {
     const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -489,9 +488,56 @@ __device__ __forceinline__ void rope8(u32x4 &lo, u32x4 &hi, const float4 &c0, co
     hi = __builtin_bit_cast(u32x4, b);
 }
 
+// K/V preparation, once per (frame, head, 64-token tile) instead of once per query tile inside attention:
+// RoPE on K in place, and V written transposed + zero padded: vt (B, H, 64, Tp), Tp = 64 * ceil(T / 64).
+__global__ __launch_bounds__(256) void kv_prep_kernel(bf16 *__restrict__ k, const bf16 *__restrict__ v, bf16 *__restrict__ vt,
+                                                       const float *__restrict__ cosb, const float *__restrict__ sinb, int T, int Tp) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];      // [token][d], 66-element rows
+    const int tid = threadIdx.x, head = blockIdx.y;
+    const long long f = blockIdx.z;
+    const long long bh = (f * VH + head) * (long long)T;
+    const int t0 = blockIdx.x * 64;
+    const int key = t0 + (tid >> 2), pr = tid & 3;
+    if (key < T) {
+        const long long off = (bh + key) * VHD + pr * 8;
+        if (key >= VPREFIX) {
+            u32x4 lo = *reinterpret_cast<const u32x4 *>(k + off), hi = *reinterpret_cast<const u32x4 *>(k + off + 32);
+            const float *c = cosb + (long long)(key - VPREFIX) * VHD + pr * 8, *sn = sinb + (long long)(key - VPREFIX) * VHD + pr * 8;
+            rope8(lo, hi, *reinterpret_cast<const float4 *>(c), *reinterpret_cast<const float4 *>(c + 4),
+                  *reinterpret_cast<const float4 *>(sn), *reinterpret_cast<const float4 *>(sn + 4));
+            *reinterpret_cast<u32x4 *>(k + off) = lo;
+            *reinterpret_cast<u32x4 *>(k + off + 32) = hi;
+        }
+    }
+    // V tile -> LDS (natural), then each thread gathers 16 tokens of one d and writes two 16-B pieces of vt[d][t0..]
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = tid + 256 * i, tk = c >> 3, dc = c & 7;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (t0 + tk < T) val = *reinterpret_cast<const u32x4 *>(v + (bh + t0 + tk) * VHD + dc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[tk * 66 + dc * 8 + j] = (unsigned short)(val[j >> 1] >> (16 * (j & 1)));
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, part = tid & 3;
+        u32x4 o[2];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const unsigned a = tile[(part * 16 + j) * 66 + d], b = tile[(part * 16 + j + 1) * 66 + d];
+            o[j >> 3][(j >> 1) & 3] = a | (b << 16);
+        }
+        bf16 *dst = vt + ((f * VH + head) * VHD + d) * (long long)Tp + t0 + part * 16;
+        *reinterpret_cast<u32x4 *>(dst) = o[0];
+        *reinterpret_cast<u32x4 *>(dst + 8) = o[1];
+    }
+}
+
+// Flash-style attention, one workgroup = 128 queries of one (frame, head), 4 waves x 32 queries, keys in tiles of 64.
+// q arrives pre-scaled by log2(e)/sqrt(64) (QKV epilogue), k already rotated, vt already transposed.
 __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, const bf16 *__restrict__ k,
-                                                    const bf16 *__restrict__ v, const float *__restrict__ cosb,
-                                                    const float *__restrict__ sinb, bf16 *__restrict__ o, int T) {
+                                                    const bf16 *__restrict__ vt, const float *__restrict__ cosb,
+                                                    const float *__restrict__ sinb, bf16 *__restrict__ o, int T, int Tp) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[2][AKT * KLD];
     __shared__ __attribute__((aligned(16))) bf16 Vt[2][VHD * VLD];
     __shared__ __attribute__((aligned(16))) float bc[4][32];
@@ -499,6 +545,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
     const int head = blockIdx.y;
     const long long f = blockIdx.z;
     const long long bh = (f * VH + head) * (long long)T;
+    const bf16 *vth = vt + (f * VH + head) * (long long)VHD * Tp;
     const int i0 = blockIdx.x * AQ + wave * 32;
     const int qi = min(i0 + r, T - 1);
 
@@ -507,7 +554,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
         u32x4 qraw[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) qraw[ks] = *reinterpret_cast<const u32x4 *>(q + (bh + qi) * VHD + ks * 16 + 8 * h);
-        if (qi >= VPREFIX) {
+        if (qi >= VPREFIX) {   // element d of this lane's fragment ks is 16*ks + 8h + j; its partner d + 32 sits in fragment ks + 2
             const float *c = cosb + (long long)(qi - VPREFIX) * VHD + 8 * h, *sn = sinb + (long long)(qi - VPREFIX) * VHD + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
@@ -518,36 +565,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
         for (int ks = 0; ks < 4; ks++) qf[ks] = __builtin_bit_cast(bf16x8, qraw[ks]);
     }
 
-    // staging: thread (key = tid>>2, pr = tid&3) moves the 16-B chunks pr and pr+4 (elements d and d+32) of K and V
-    const int skey = tid >> 2, spr = tid & 3;
+    // staging: 512 16-byte pieces of K (key rows) and 512 of V^T (d rows) per tile, two of each per thread
     u32x4 rk[2], rv[2];
-    float4 kcs[2], ksn[2];
 #define A_LOAD(kt)                                                                                   \
-    {                                                                                                \
-        const int key = (kt) * AKT + skey;                                                           \
-        const bool ok = key < T;                                                                     \
-        const long long off = (bh + (ok ? key : 0)) * VHD + spr * 8;                                 \
-        const unsigned msk = ok ? 0xffffffffu : 0u;                                                  \
-        rk[0] = *reinterpret_cast<const u32x4 *>(k + off) & msk;                                     \
-        rk[1] = *reinterpret_cast<const u32x4 *>(k + off + 32) & msk;                                \
-        rv[0] = *reinterpret_cast<const u32x4 *>(v + off) & msk;                                     \
-        rv[1] = *reinterpret_cast<const u32x4 *>(v + off + 32) & msk;                                \
-        const int pos = (ok && key >= VPREFIX) ? key - VPREFIX : 0;                                  \
-        const float *c_ = cosb + (long long)pos * VHD + spr * 8, *s_ = sinb + (long long)pos * VHD + spr * 8; \
-        kcs[0] = *reinterpret_cast<const float4 *>(c_);                                               \
-        kcs[1] = *reinterpret_cast<const float4 *>(c_ + 4);                                           \
-        ksn[0] = *reinterpret_cast<const float4 *>(s_);                                               \
-        ksn[1] = *reinterpret_cast<const float4 *>(s_ + 4);                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+        const int c = tid + 256 * i, row = c >> 3, pc = c & 7;                                       \
+        const int key = (kt) * AKT + row;                                                            \
+        const unsigned msk = key < T ? 0xffffffffu : 0u;                                             \
+        rk[i] = *reinterpret_cast<const u32x4 *>(k + (bh + min(key, T - 1)) * VHD + pc * 8) & msk;   \
+        rv[i] = *reinterpret_cast<const u32x4 *>(vth + (long long)row * Tp + (kt) * AKT + pc * 8);   \
     }
-#define A_STORE(buf, kt)                                                                             \
-    {                                                                                                \
-        if ((kt) * AKT + skey >= VPREFIX) rope8(rk[0], rk[1], kcs[0], kcs[1], ksn[0], ksn[1]);           \
-        *reinterpret_cast<u32x4 *>(&Ks[buf][skey * KLD + spr * 8]) = rk[0];                          \
-        *reinterpret_cast<u32x4 *>(&Ks[buf][skey * KLD + spr * 8 + 32]) = rk[1];                     \
-        unsigned short *vt = reinterpret_cast<unsigned short *>(&Vt[buf][0]);                        \
-        _Pragma("unroll") for (int i = 0; i < 2; i++)                                                \
-            _Pragma("unroll") for (int j = 0; j < 8; j++)                                            \
-                vt[(spr * 8 + 32 * i + j) * VLD + skey] = (unsigned short)(rv[i][j >> 1] >> (16 * (j & 1))); \
+#define A_STORE(buf)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
+        const int c = tid + 256 * i, row = c >> 3, pc = c & 7;                                       \
+        *reinterpret_cast<u32x4 *>(&Ks[buf][row * KLD + pc * 8]) = rk[i];                            \
+        unsigned long long *vd = reinterpret_cast<unsigned long long *>(&Vt[buf][row * VLD + pc * 8]); \
+        vd[0] = (unsigned long long)rv[i][0] | ((unsigned long long)rv[i][1] << 32);                 \
+        vd[1] = (unsigned long long)rv[i][2] | ((unsigned long long)rv[i][3] << 32);                 \
     }
 
     f32x16 oacc[2];
@@ -559,13 +593,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
 
     const int ntile = (T + AKT - 1) / AKT;
     A_LOAD(0);
-    A_STORE(0, 0);
+    A_STORE(0);
     __syncthreads();
     for (int kt = 0; kt < ntile; kt++) {
         if (kt + 1 < ntile) A_LOAD(kt + 1);
         const bf16 *Kb = &Ks[kt & 1][0];
         const bf16 *Vb = &Vt[kt & 1][0];
-        // S^T tiles: rows = keys, cols = queries
+        // S^T tiles: rows = keys, cols = queries (already in the log2 domain)
         f32x16 st[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -577,46 +611,48 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
                 st[j] = mfma_bf16(ka, qf[ks], st[j]);
             }
         }
-        // online softmax over keys (base-2 exponentials; q was pre-scaled by 1/sqrt(64))
-        float mt = -INFINITY;
+        if (kt + 1 == ntile) {       // only the last tile has keys beyond T
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int key = kt * AKT + j * 32 + crow(e, h);
-                const float s = key < T ? st[j][e] * LOG2E : -INFINITY;
-                st[j][e] = s;
-                mt = fmaxf(mt, s);
-            }
+                for (int e = 0; e < 16; e++)
+                    if (kt * AKT + j * 32 + crow(e, h) >= T) st[j][e] = -INFINITY;
+        }
+        float mt = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int e = 1; e < 16; e++) mt = fmaxf(mt, fmaxf(st[0][e], st[1][e]));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float mn = fmaxf(m, mt);
-        const float alpha = exp2f(m - mn);
         float rs = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float p = exp2f(st[j][e] - mn);
+                const float p = __builtin_amdgcn_exp2f(st[j][e] - mn);
                 st[j][e] = p;
                 rs += p;
             }
         rs += __shfl_xor(rs, 32);
-        l = l * alpha + rs;
-        m = mn;
-        // rescale O: alpha lives on the query's lane, O rows are queries -> broadcast through LDS (wave-local)
-        if (h == 0) bc[wave][r] = alpha;
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS write has landed
+        if (__any(mn != m)) {
+            // rescale O: alpha lives on the query's lane, O rows are queries -> broadcast through LDS (wave-local)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+            if (h == 0) bc[wave][r] = alpha;
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS write has landed
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(&bc[wave][8 * g4 + 4 * h]);
+            for (int g4 = 0; g4 < 4; g4++) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(&bc[wave][8 * g4 + 4 * h]);
 #pragma unroll
-            for (int dt = 0; dt < 2; dt++) {
-                oacc[dt][4 * g4 + 0] *= a4.x;
-                oacc[dt][4 * g4 + 1] *= a4.y;
-                oacc[dt][4 * g4 + 2] *= a4.z;
-                oacc[dt][4 * g4 + 3] *= a4.w;
+                for (int dt = 0; dt < 2; dt++) {
+                    oacc[dt][4 * g4 + 0] *= a4.x;
+                    oacc[dt][4 * g4 + 1] *= a4.y;
+                    oacc[dt][4 * g4 + 2] *= a4.z;
+                    oacc[dt][4 * g4 + 3] *= a4.w;
+                }
             }
+            m = mn;
         }
+        l += rs;
         // P.V: P^T tile registers 8*s2..8*s2+7 are the A fragment of k-step s2 (key order 16*s2 + 8*(j>>2) + 4h + (j&3))
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -635,7 +671,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
                     oacc[dt] = mfma_bf16(pa, vb, oacc[dt]);
                 }
             }
-        if (kt + 1 < ntile) A_STORE((kt + 1) & 1, kt + 1);
+        if (kt + 1 < ntile) A_STORE((kt + 1) & 1);
         __syncthreads();
     }
 #undef A_LOAD
@@ -684,6 +720,7 @@ extern "C" long long sslam_vit_workspace_bytes(int n_frames, int size) {
     b += ws_align(rows * VD * 4);                 // x   fp32 residual stream
     b += ws_align(rows * VD * 2);                 // y   bf16 LN output / attention output
     b += ws_align(rows * VD * 2 * 3);             // q, k, v bf16
+    b += ws_align((long long)n_frames * VD * ((T + 63) / 64 * 64) * 2);   // v transposed + padded
     b += ws_align(rows * VMLP * 2);               // h   bf16 MLP hidden (also the patch matrix)
     return (long long)b;
 }
@@ -701,6 +738,8 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
     float *x = (float *)p;            p += ws_align(rows * VD * 4);
     bf16 *y = (bf16 *)p;              p += ws_align(rows * VD * 2);
     bf16 *q = (bf16 *)p;              bf16 *k = q + rows * VD, *v = k + rows * VD;   p += ws_align(rows * VD * 2 * 3);
+    const int Tp = (T + 63) / 64 * 64;
+    bf16 *vt = (bf16 *)p;             p += ws_align((long long)n_frames * VD * Tp * 2);
     bf16 *hbuf = (bf16 *)p;
 
     // patch embedding + prefix tokens
@@ -719,12 +758,13 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
         const sslam_vit_layer_t &ly = w->layer[L];
         hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, (void *)y);
         launch_ares<1>(y, (const bf16 *)ly.wqkv, rows, 3 * VD, VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st);
-        hipLaunchKernelGGL(attn_kernel, dim3((T + AQ - 1) / AQ, VH, n_frames), dim3(256), 0, st, q, k, v, w->rope_cos, w->rope_sin, y, T);
+        hipLaunchKernelGGL(kv_prep_kernel, dim3(Tp / 64, VH, n_frames), dim3(256), 0, st, k, v, vt, w->rope_cos, w->rope_sin, T, Tp);
+        hipLaunchKernelGGL(attn_kernel, dim3((T + AQ - 1) / AQ, VH, n_frames), dim3(256), 0, st, q, k, vt, w->rope_cos, w->rope_sin, y, T, Tp);
         launch_ares<1>(y, (const bf16 *)ly.wo, rows, VD, VD, EpiResidual{ly.bo, ly.ls1, x}, st);
         hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, (void *)y);
         launch_ares<1>(y, (const bf16 *)ly.wup, rows, VMLP, VD, EpiGelu{ly.bup, hbuf, VMLP}, st);
         launch_ares<1>(hbuf, (const bf16 *)ly.wdown, rows, VD, VMLP, EpiResidual{ly.bdown, ly.ls2, x}, st);
-        g_sslam_launches += 7;
+        g_sslam_launches += 8;
     }
     hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, (void *)tokens_out);
     SSLAM_CHECK_LAUNCH();

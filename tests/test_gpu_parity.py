@@ -390,4 +390,4 @@ def test_pipeline_with_hip_vit_end_to_end(T, hip):
     before = hip.launch_count()
     with T.no_grad():
         f = bb(pipe.preprocess(imgs[:2]))
-    assert f.shape == (2, 28, 28, 384) and hip.launch_count() >= before + 80      # 12 layers x 7 launches
+    assert f.shape == (2, 28, 28, 384) and hip.launch_count() >= before + 90      # 12 layers x 8 launches
