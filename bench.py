@@ -223,11 +223,14 @@ def main():
         conv_flop = n * cells * pipe.selector.hidden * (9 * 384) * 2 + n * cells * pipe.selector.hidden * 2
         conv_s = stage_ms["A3_selector_saliency"] * 1e-3
         achieved = conv_flop / conv_s / 1e12
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (FETCH_SIZE / WRITE_SIZE with
+        # the gfx950 corrections of MI355X_MICROARCH.md, tools/pmc_summary.py); the committed summary is keyed by workload
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_selector_traffic.json")
-        if os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and args.workload == "fr1_desk_613" and not args.frames:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                k = [v for name, v in json.load(open(pmc)).items() if name.startswith("selector_saliency")][0]
+                traffic = int(k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"])
             except Exception:
                 traffic = None
         # parity spot-check against the oracle on the first frames (outside the timed region)
@@ -249,6 +252,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "selector_saliency_kernel (A3 conv3x3 implicit GEMM, fp32 MFMA)",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "algorithmic_bytes": n * cells * 384 * 4 + n * cells * 4 + 9 * 384 * pipe.selector.hidden * 4,
                          "flop_per_launch": conv_flop, "launch_ms": stage_ms["A3_selector_saliency"]},
             "stage_ms": stage_ms,
             "parity": {"frames_checked_vs_oracle": nchk, "bit_exact": ok},

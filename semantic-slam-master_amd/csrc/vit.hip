@@ -121,7 +121,7 @@ constexpr int RM128 = 32 * MT, KC = 384, ALD2 = KC + 8, KSTEPS = KC / 16, A_PIEC
 constexpr int BRING = SSLAM_BRING;   // B fragments in flight per wave (1 KB each): Little's law needs >= 32 KB per CU
 
 template <int S, class Epi>
-__global__ __launch_bounds__(256, MT == 2 ? ARES_OCC : 1) void gemm_ares_kernel(const bf16 *__restrict__ A, const bf16 *__restrict__ Wp, int M, int N,
+__global__ __launch_bounds__(256, MT <= 3 ? ARES_OCC : 1) void gemm_ares_kernel(const bf16 *__restrict__ A, const bf16 *__restrict__ Wp, int M, int N,
                                                             int K, int n_items, int n_groups, Epi epi) {
     __shared__ __attribute__((aligned(16))) bf16 As[RM128 * ALD2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -704,7 +704,7 @@ void launch_gemm(const bf16 *A, const bf16 *W, long long M, int N, int K, Epi ep
 template <int S, class Epi>
 void launch_ares(const bf16 *A, const bf16 *Wp, long long M, int N, int K, Epi epi, hipStream_t st) {
     const int n_groups = N / (128 * S), n_tiles = (int)((M + RM128 - 1) / RM128), n_items = n_tiles * n_groups;
-    const int slots = MT == 2 ? 256 * ARES_OCC : 256;                  // persistent workgroups: 3 per CU at 64 rows, 1 at 128
+    const int slots = MT <= 3 ? 256 * ARES_OCC : 256;                  // persistent workgroups: 3 per CU at 64 rows, 1 at 128
     const int grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL((gemm_ares_kernel<S, Epi>), dim3(grid), dim3(256), 0, st, A, Wp, (int)M, N, K, n_items, n_groups, epi);
 }
