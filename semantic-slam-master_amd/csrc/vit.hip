@@ -8,10 +8,10 @@
 //
 // Per layer: LN1 -> [QKV GEMM + bias + RoPE + 1/sqrt(d) scale, scattered to (B, H, T, 64)] -> flash-style attention ->
 // [o_proj GEMM + bias, LayerScale, residual add in place] -> LN2 -> [up GEMM + bias + exact GELU] ->
-// [down GEMM + bias, LayerScale, residual add].  One generic 128x128x64 bf16 GEMM (4 waves, register double-buffered
-// LDS staging, 144-B padded rows) with the epilogue as a template functor; torch's nn.Linear weight layout (N, K) is
-// consumed as is.  Attention keeps the query on the lane (S^T = K.Q^T), so the running max / sum are lane-local and the
-// probability tile is fed to the P.V MFMA straight from the accumulator registers (no LDS round trip for P).
+// [down GEMM + bias, LayerScale, residual add].  One "A-resident" bf16 GEMM (below) with the epilogue as a template
+// functor; weights are pre-packed into MFMA B-fragment order.  Attention keeps the query on the lane (S^T = K.Q^T), so the
+// running max / sum are lane-local and the probability tile is fed to the P.V MFMA straight from the accumulator
+// registers (no LDS round trip for P); K is rotated and V transposed once per layer by kv_prep_kernel.
 #include "common.h"
 
 typedef __bf16 bf16;
@@ -26,75 +26,6 @@ constexpr float LOG2E = 1.44269504088896341f;
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------------ GEMM
-constexpr int GM = 128, GN = 128, GK = 64, GLD = GK + 8;   // 144-B LDS rows
-
-template <class Epi>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16 *__restrict__ A, const bf16 *__restrict__ W, int M, int N, int K,
-                                                         Epi epi) {
-    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (GM + GN) * GLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * GN, m0 = blockIdx.y * GM;
-    const int nk = K / GK;
-
-    u32x4 ra[4], rb[4];
-    const bf16 *ap[4], *bp[4];
-    int so[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-        ap[i] = A + (long long)min(m0 + row, M - 1) * K + kc * 8;
-        bp[i] = W + (long long)(n0 + row) * K + kc * 8;
-        so[i] = row * GLD + kc * 8;
-    }
-#define G_LOAD(s)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; i++) {                                      \
-        ra[i] = *reinterpret_cast<const u32x4 *>(ap[i] + (s) * GK);                      \
-        rb[i] = *reinterpret_cast<const u32x4 *>(bp[i] + (s) * GK);                      \
-    }
-#define G_STORE(buf)                                                                     \
-    {                                                                                    \
-        bf16 *As_ = smem + (buf) * (GM + GN) * GLD, *Bs_ = As_ + GM * GLD;               \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                  \
-            *reinterpret_cast<u32x4 *>(As_ + so[i]) = ra[i];                             \
-            *reinterpret_cast<u32x4 *>(Bs_ + so[i]) = rb[i];                             \
-        }                                                                                \
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[mi][ni][e] = 0.0f;
-
-    G_LOAD(0);
-    G_STORE(0);
-    __syncthreads();
-    for (int s = 0; s < nk; s++) {
-        if (s + 1 < nk) G_LOAD(s + 1);
-        const bf16 *As = smem + (s & 1) * (GM + GN) * GLD + (wm * 64 + r) * GLD + 8 * h;
-        const bf16 *Bs = smem + (s & 1) * (GM + GN) * GLD + GM * GLD + (wn * 64 + r) * GLD + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < GK / 16; ks++) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(As + ks * 16);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(As + 32 * GLD + ks * 16);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(Bs + ks * 16);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(Bs + 32 * GLD + ks * 16);
-            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
-        }
-        if (s + 1 < nk) G_STORE((s + 1) & 1);
-        __syncthreads();
-    }
-#undef G_LOAD
-#undef G_STORE
-    epi.tile(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
 }
 
 // ------------------------------------------------------------------------------- A-resident GEMM (K in chunks of 384)
@@ -189,9 +120,7 @@ __global__ __launch_bounds__(256, MT <= 3 ? ARES_OCC : 1) void gemm_ares_kernel(
                         for (int mt = 0; mt < MT; mt++)
                             an[mt] = *reinterpret_cast<const bf16x8 *>(Ab + mt * 32 * ALD2 + (ks + 1) * 16);
                     }
-#ifndef SSLAM_DBG_NOB
                     if (ks + BRING < KSTEPS) bq[ks % BRING] = bsrc[(ks + BRING) * 64];
-#endif
                     if (s == 0 && have_next && ks < A_PIECES) pre[ks] = *A_SRC(nrt, nkc, ks);
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) acc[s][mt] = mfma_bf16(ac[mt], bnow, acc[s][mt]);
@@ -207,12 +136,7 @@ __global__ __launch_bounds__(256, MT <= 3 ? ARES_OCC : 1) void gemm_ares_kernel(
                 // epilogue of the item (registers only)
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-#ifdef SSLAM_DBG_NOEPI
-#pragma unroll
-                    for (int mt = 0; mt < 4; mt++) asm volatile("" ::"v"(acc[s][mt]));
-#else
                     epi.slice(acc[s], rt * RM128, (ng * (4 * S) + s * 4 + wave) * 32, r, h, M);
-#endif
                 }
             }
             if (have_next) __syncthreads();
@@ -243,23 +167,6 @@ struct EpiResidual {
                 }
             }
     }
-    __device__ __forceinline__ void tile(f32x16 (&acc)[2][2], int row0, int col0, int r, int h, int M) const {
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int col = col0 + ni * 32 + r;
-            const float b = bias[col], l = ls[col];
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = row0 + mi * 32 + crow(e, h);
-                    if (row < M) {
-                        float *p = x + (long long)row * VD + col;
-                        *p = *p + l * (acc[mi][ni][e] + b);
-                    }
-                }
-        }
-    }
 };
 
 // out[row, col] = gelu(acc + bias[col]) as bf16       (up_proj; exact erf GELU = torch's default)
@@ -283,23 +190,6 @@ struct EpiGelu {
                     base[(long long)o * ldo] = (bf16)(0.5f * v * (1.0f + erff(v * 0.70710678118654752f)));
                 }
             }
-    }
-    __device__ __forceinline__ void tile(f32x16 (&acc)[2][2], int row0, int col0, int r, int h, int M) const {
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int col = col0 + ni * 32 + r;
-            const float b = bias[col];
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = row0 + mi * 32 + crow(e, h);
-                    if (row < M) {
-                        const float v = acc[mi][ni][e] + b;
-                        out[(long long)row * ldo + col] = (bf16)(0.5f * v * (1.0f + erff(v * 0.70710678118654752f)));
-                    }
-                }
-        }
     }
 };
 
@@ -329,23 +219,6 @@ struct EpiPatch {
                 }
             }
     }
-    __device__ __forceinline__ void tile(f32x16 (&acc)[2][2], int row0, int col0, int r, int h, int M) const {
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int col = col0 + ni * 32 + r;
-            const float b = bias[col];
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = row0 + mi * 32 + crow(e, h);
-                    if (row < M) {
-                        const int f = row / cells, p = row - f * cells;
-                        x[((long long)f * T + VPREFIX + p) * VD + col] = acc[mi][ni][e] + b;
-                    }
-                }
-        }
-    }
 };
 
 // QKV: + bias, RoPE on the patch tokens of q and k (pairs (d, d+32) are the two N tiles of this wave), q *= 1/8,
@@ -371,34 +244,6 @@ struct EpiQKV {
             for (int e = 0; e < 16; e++) {
                 const int o = mt * 32 + (e & 3) + 8 * (e >> 2);
                 if (row0 + o + 4 * h < M) base[(long long)o * VHD + (o >= wrap ? fstep : 0)] = (bf16)((acc[mt][e] + b) * sc);
-            }
-    }
-    __device__ __forceinline__ void tile(f32x16 (&acc)[2][2], int row0, int col0, int r, int h, int M) const {
-        const int which = col0 / VD, head = (col0 % VD) / VHD;
-        bf16 *dst = which == 0 ? q : (which == 1 ? k : v);
-        const float b0 = bias[col0 + r], b1 = bias[col0 + 32 + r];
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = row0 + mi * 32 + crow(e, h);
-                if (row < M) {
-                    const int f = row / T, t = row - f * T;
-                    float x0 = acc[mi][0][e] + b0, x1 = acc[mi][1][e] + b1;
-                    if (which < 2 && t >= VPREFIX) {
-                        const float *c = cosb + (long long)(t - VPREFIX) * VHD, *s = sinb + (long long)(t - VPREFIX) * VHD;
-                        const float y0 = x0 * c[r] - x1 * s[r], y1 = x1 * c[32 + r] + x0 * s[32 + r];
-                        x0 = y0;
-                        x1 = y1;
-                    }
-                    if (which == 0) {
-                        x0 *= 0.125f * LOG2E;
-                        x1 *= 0.125f * LOG2E;
-                    }
-                    bf16 *p = dst + (((long long)f * VH + head) * T + t) * VHD;
-                    p[r] = (bf16)x0;
-                    p[32 + r] = (bf16)x1;
-                }
             }
     }
 };
@@ -693,11 +538,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
             }
         }
     }
-}
-
-template <class Epi>
-void launch_gemm(const bf16 *A, const bf16 *W, long long M, int N, int K, Epi epi, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), dim3(N / GN, (unsigned)((M + GM - 1) / GM)), dim3(256), 0, st, A, W, (int)M, N, K, epi);
 }
 
 // A-resident persistent GEMM: one workgroup per CU walks (row tile, column group) items
