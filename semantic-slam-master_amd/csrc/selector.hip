@@ -131,6 +131,16 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
     // direct-B: lane's fragment of (stage s, k-group g, tile ni) = 16 B at (((s*4+g)*HS + n)*8 + 4h) floats
     const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 32 * NI + r) * 2 + h);
 
+    // B fragments are one continuous stream over (stage, k-group) in the packed weights: slot g of the ring always holds
+    // k-group g of the current stage and is refilled with k-group g of the NEXT stage right after its MFMAs, i.e. every
+    // fragment is requested one full stage (>= 4096 matrix-pipe cycles) before it is needed.
+    f32x4 bq[BK / 8][NI];
+    if (BDIRECT) {
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)g * HS + ni * 32) * 2];
+    }
     LOAD_STAGE(0);
     STORE_STAGE(0);
     __syncthreads();
@@ -138,13 +148,6 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
         if (s + 1 < NSTAGE) LOAD_STAGE(s + 1);
         const float *As = smem + (s & 1) * STAGE_FLOATS + (wm * 64 + r) * LDT + 4 * h;
         const float *Bs = smem + (s & 1) * STAGE_FLOATS + BM * LDT + (wn * 32 * NI + r) * LDT + 4 * h;
-        f32x4 bq[BK / 8][NI];
-        if (BDIRECT) {
-#pragma unroll
-            for (int g = 0; g < BK / 8; g++)
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)(s * (BK / 8) + g) * HS + ni * 32) * 2];
-        }
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(As + 8 * g);
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
                 b[ni] = BDIRECT ? bq[g][ni] : *reinterpret_cast<const f32x4 *>(Bs + ni * 32 * LDT + 8 * g);
+            if (BDIRECT && s + 1 < NSTAGE) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)((s + 1) * (BK / 8) + g) * HS + ni * 32) * 2];
+            }
 #pragma unroll
             for (int st = 0; st < 4; st++)
 #pragma unroll
