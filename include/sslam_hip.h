@@ -80,6 +80,16 @@ int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int
 int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
                             const float *w2, const float *b2, int hs, float *sal, void *stream);
 
+/* ---- A3, bf16 THROUGHPUT mode (BASELINE.json configs[1] "bf16 conv stack").  Same layer as
+ * sslam_selector_saliency with bf16 operands (round-to-nearest-even), fp32 accumulation on v_mfma_f32_32x32x16_bf16 and
+ * the fp32 epilogue.  NOT index-exact against the fp32 reference: callers report the agreement rate next to it.
+ * sslam_f32_to_bf16: the bf16 copy of the feature map (n % 8 == 0, 16-byte aligned pointers).
+ * sslam_pack_conv3x3_bf16_host: w (hs,384,3,3) fp32 -> 9*384*hs bf16 in MFMA-fragment order. */
+int sslam_f32_to_bf16(const float *in, void *out_bf16, long long n, void *stream);
+int sslam_pack_conv3x3_bf16_host(const float *w_host, int hs, void *out_bf16_host);
+int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames, int G, const void *w1_packed_bf16, const float *b1,
+                                 const float *w2, const float *b2, int hs, float *sal, void *stream);
+
 /* ---- A4 + A5 (+ A8): NMS + percentile threshold + branchy top-k.  Replaces KeypointSelector.select_keypoints /
  * _apply_nms, keypoint_selector.py:69-226, and DinoBackbone.patch_to_pixel, dino_backbone.py:154-165.
  * sal (n_frames, G, G) -> kp_xy (n_frames, K, 2) fp32 (x, y) patch units; scores (n_frames, K);
@@ -115,6 +125,17 @@ int sslam_refine(const float *x, long long rows, const float *packed, int n_bloc
 /* ---- A6 + A7 fused: gather straight into the MLP's LDS tile (the pipeline's fast path). */
 int sslam_gather_refine(const float *feat, int n_frames, int G, const float *kp_xy, int K, const float *packed,
                         int n_blocks, float *desc, void *stream);
+
+/* ---- A6 + A7, bf16 THROUGHPUT mode (BASELINE.json configs[1]): the same gather + MLP with bf16
+ * GEMM operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation / residual / LayerNorm statistics / L2 normalisation;
+ * LayerNorm is folded into the following GEMM (W*gamma, column sums, b + W beta are precomputed by the packer).
+ * NOT bit-exact against the fp32 reference.  packed_bf16: sslam_refiner_bf16_bytes(n_blocks) bytes written by
+ * sslam_refiner_pack_bf16_host from the same pointer list as sslam_refiner_pack_host. */
+long long sslam_refiner_bf16_bytes(int n_blocks);
+int sslam_refiner_pack_bf16_host(const float *const *w_host, int n_blocks, void *out_host);
+int sslam_refine_bf16(const float *x, long long rows, const void *packed_bf16, int n_blocks, float *desc, void *stream);
+int sslam_gather_refine_bf16(const float *feat, int n_frames, int G, const float *kp_xy, int K, const void *packed_bf16,
+                             int n_blocks, float *desc, void *stream);
 
 /* ---- A9: per-keypoint intensity.  Replaces visualize_matches_sequence.py:87-95 (Pillow BICUBIC resize to
  * (size,size) -> "L" -> /255 -> gray[round(y), round(x)]); only the pixels that are looked up are resampled.

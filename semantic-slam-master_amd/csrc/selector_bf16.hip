@@ -1,0 +1,218 @@
+// selector_bf16.hip - A3 in the bf16 THROUGHPUT mode (BASELINE.json configs[1] "bf16 conv stack"):
+// the saliency CNN of keypoint_selector.py:45-67 with bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation and
+// the same fused fp32 epilogue (bias start, ReLU, 1x1 conv tree, canonical sigmoid) as the exact kernel (selector.hip).
+// NOT index-exact against the fp32 CPU reference by construction (operands are rounded to 8 significant bits): the
+// host layer reports the keypoint / match agreement with the exact mode next to the throughput.  Deterministic.
+//
+// Same implicit-GEMM structure as selector.hip: M = cells, N = hs, K = 3456 chunk-major in 27 stages of 128 channels
+// (3 channel chunks x 9 taps); A rows come from a bf16 copy of the feature map (written by sslam_bn_tokens) through a
+// register-double-buffered LDS stage (272-B rows), B fragments stream from L2 in fragment order, 4 k-steps ahead.
+// With 16x the matrix rate the kernel is bound by the A-tile traffic (9 L1/L2 re-reads of 256 B per row and stage).
+#include "common.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BKB = 128;                 // channels per stage
+constexpr int LDB = BKB + 8;             // LDS row (bf16 elements): 272 B = 17 x 16 B
+constexpr int NSTB = 9 * (SSLAM_C / BKB);
+constexpr int KSB = BKB / 16;            // MFMA k-steps per stage
+constexpr int RING = 4;
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
+                                                             const bf16 *__restrict__ w1p, const float *__restrict__ b1,
+                                                             const float *__restrict__ w2, const float *__restrict__ b2,
+                                                             float *__restrict__ sal, int n_tiles) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int BM = 64 * WM, HS = 64 * WN, NSLAB = HS / 64;
+    constexpr int A_ITEMS = BM * (BKB / 8) / 512;          // 16-B pieces per thread per stage
+    constexpr int STAGE = BM * LDB;
+    constexpr int SMEM = 2 * STAGE * 2 > NSLAB * BM * 4 ? 2 * STAGE * 2 : NSLAB * BM * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM];
+    bf16 *smem = reinterpret_cast<bf16 *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cells = G * G;
+    int tile;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+    }
+    const long long m0 = (long long)tile * BM;
+
+    int a_row[A_ITEMS], a_pc[A_ITEMS], a_y[A_ITEMS], a_x[A_ITEMS];
+    const bf16 *a_base[A_ITEMS];
+    bool a_ok[A_ITEMS];
+#pragma unroll
+    for (int i = 0; i < A_ITEMS; i++) {
+        const int it = tid + 512 * i;
+        a_row[i] = it / (BKB / 8);
+        a_pc[i] = it % (BKB / 8);
+        const long long m = m0 + a_row[i];
+        a_ok[i] = m < n_rows;
+        const long long mm = a_ok[i] ? m : 0;
+        const int f = (int)(mm / cells), cell = (int)(mm % cells);
+        a_y[i] = cell / G;
+        a_x[i] = cell % G;
+        a_base[i] = feat + (long long)f * cells * SSLAM_C + a_pc[i] * 8;
+    }
+    u32x4 ra[A_ITEMS];
+#define LOAD_STAGE(S)                                                                                        \
+    {                                                                                                        \
+        const int s_ = (S);                                                                                  \
+        const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                      \
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                \
+            const int yy = a_y[i] + dy, xx = a_x[i] + dx;                                                    \
+            const bool ok = a_ok[i] && yy >= 0 && yy < G && xx >= 0 && xx < G;                               \
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(                                                \
+                a_base[i] + (ok ? ((long long)yy * G + xx) * SSLAM_C + chunk * BKB : 0));                    \
+            ra[i] = v & (ok ? 0xffffffffu : 0u);                                                             \
+        }                                                                                                    \
+    }
+#define STORE_STAGE(BUF)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++)                                                      \
+        *reinterpret_cast<u32x4 *>(smem + (BUF) * STAGE + a_row[i] * LDB + a_pc[i] * 8) = ra[i];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+        const float bv = b1[wn * 64 + ni * 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
+    }
+    // B fragment (global k-step G = stage*8 + ks, N tile t): 16 B per lane at ((G * (HS/32) + t) * 64 + lane)
+    const bf16x8 *bsrc = reinterpret_cast<const bf16x8 *>(w1p) + (wn * 2) * 64 + lane;
+    constexpr int GSTR = (HS / 32) * 64;           // bf16x8 elements per global k-step
+    bf16x8 bq[RING][2];
+#pragma unroll
+    for (int i = 0; i < RING; i++) {
+        bq[i][0] = bsrc[(long long)i * GSTR];
+        bq[i][1] = bsrc[(long long)i * GSTR + 64];
+    }
+    LOAD_STAGE(0);
+    STORE_STAGE(0);
+    __syncthreads();
+    for (int s = 0; s < NSTB; s++) {
+        if (s + 1 < NSTB) LOAD_STAGE(s + 1);
+        const bf16 *As = smem + (s & 1) * STAGE + (wm * 64 + r) * LDB + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KSB; ks++) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(As + ks * 16);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(As + 32 * LDB + ks * 16);
+            const bf16x8 b0 = bq[ks % RING][0], b1v = bq[ks % RING][1];
+            const long long gn = (long long)s * KSB + ks + RING;
+            if (gn < (long long)NSTB * KSB) {
+                bq[ks % RING][0] = bsrc[gn * GSTR];
+                bq[ks % RING][1] = bsrc[gn * GSTR + 64];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1v, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1v, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < NSTB) STORE_STAGE((s + 1) & 1);
+        __syncthreads();
+    }
+#undef LOAD_STAGE
+#undef STORE_STAGE
+    // epilogue identical to the exact kernel: ReLU, 1x1 conv tree, sigmoid (fp32)
+    float *red = reinterpret_cast<float *>(smem_raw);
+    {
+        const float w2a = w2[wn * 64 + r], w2b = w2[wn * 64 + 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[mi][0][e] > 0.0f ? acc[mi][0][e] : 0.0f;
+                const float h1 = acc[mi][1][e] > 0.0f ? acc[mi][1][e] : 0.0f;
+                const float t = bfly32(h0 * w2a + h1 * w2b);
+                if (r == 0) red[wn * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+            }
+    }
+    __syncthreads();
+    for (int t = tid; t < BM; t += 512) {
+        const long long m = m0 + t;
+        if (m < n_rows) {
+            float logit = b2[0];
+#pragma unroll
+            for (int sl = 0; sl < NSLAB; sl++) logit = logit + red[sl * BM + t];
+            sal[m] = sslam_sigmoid(logit);
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (bf16)v); }
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ in, bf16 *__restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = *reinterpret_cast<const float4 *>(in + 8 * i), b = *reinterpret_cast<const float4 *>(in + 8 * i + 4);
+    u32x4 o;
+    o[0] = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+    o[1] = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+    o[2] = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
+    o[3] = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+    *reinterpret_cast<u32x4 *>(out + 8 * i) = o;
+}
+
+unsigned short host_bf16(float v) {   // round-to-nearest-even, as v_cvt_pk_bf16_f32 (finite inputs)
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+}  // namespace
+
+// fp32 (n) -> bf16 (n), n % 8 == 0: the bf16 copy of the feature map consumed by sslam_selector_saliency_bf16
+extern "C" int sslam_f32_to_bf16(const float *in, void *out_bf16, long long n, void *stream) {
+    if (!in || !out_bf16 || n <= 0 || (n & 7) || (((uintptr_t)in | (uintptr_t)out_bf16) & 15)) return SSLAM_E_INVALID;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (bf16 *)out_bf16, n / 8);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}
+
+// w (hs, 384, 3, 3) fp32 -> bf16 in [stage = chunk*9 + tap][k-step (8)][n/32][half (2)][row (32)][8] order
+extern "C" int sslam_pack_conv3x3_bf16_host(const float *w, int hs, void *out_bf16) {
+    if (!w || !out_bf16 || hs <= 0 || hs % 32) return SSLAM_E_INVALID;
+    unsigned short *out = (unsigned short *)out_bf16;
+    for (int chunk = 0; chunk < SSLAM_C / BKB; chunk++)
+        for (int tap = 0; tap < 9; tap++)
+            for (int n = 0; n < hs; n++)
+                for (int k = 0; k < BKB; k++) {
+                    const int c = chunk * BKB + k, stage = chunk * 9 + tap, ks = k / 16, hh = (k % 16) / 8, j = k % 8;
+                    const long long idx = (((((long long)stage * KSB + ks) * (hs / 32) + n / 32) * 2 + hh) * 32 + n % 32) * 8 + j;
+                    out[idx] = host_bf16(w[((long long)n * SSLAM_C + c) * 9 + tap]);
+                }
+    return SSLAM_OK;
+}
+
+extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames, int G, const void *w1_packed_bf16,
+                                            const float *b1, const float *w2, const float *b2, int hs, float *sal, void *stream) {
+    if (!feat_bf16 || !w1_packed_bf16 || !b1 || !w2 || !b2 || !sal || n_frames <= 0 || G <= 0) return SSLAM_E_INVALID;
+    if (((uintptr_t)feat_bf16 | (uintptr_t)w1_packed_bf16) & 15) return SSLAM_E_INVALID;
+    const long long rows = (long long)n_frames * G * G;
+    if (rows > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hs == 256) {
+        const int n_tiles = (int)((rows + 127) / 128);
+        hipLaunchKernelGGL((selector_bf16_kernel<2, 4>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+                           (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+    } else if (hs == 128) {
+        const int n_tiles = (int)((rows + 255) / 256);
+        hipLaunchKernelGGL((selector_bf16_kernel<4, 2>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+                           (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+    } else {
+        return SSLAM_E_UNSUPPORTED;
+    }
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}

@@ -60,6 +60,8 @@ EXPORTS = [
     "sslam_select_keypoints", "sslam_gather", "sslam_refiner_layout", "sslam_refiner_pack_host", "sslam_refine",
     "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
     "sslam_vit_workspace_bytes", "sslam_vit_forward",
+    "sslam_f32_to_bf16", "sslam_pack_conv3x3_bf16_host", "sslam_selector_saliency_bf16",
+    "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
 ]
 
 
@@ -89,6 +91,14 @@ def lib():
         L.sslam_keypoint_intensity.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, i, p, p]
         L.sslam_sim_argmax.argtypes = [p, ll, i, p, ll, i, i, p, p, p, p, p, p]
         L.sslam_match_finalize.argtypes = [p, p, p, i, i, i, p, ll, p, ll, p, p, f, f, f, f, f, p, p, p, p]
+        L.sslam_f32_to_bf16.argtypes = [p, p, ll, p]
+        L.sslam_pack_conv3x3_bf16_host.argtypes = [p, i, p]
+        L.sslam_selector_saliency_bf16.argtypes = [p, i, i, p, p, p, p, i, p, p]
+        L.sslam_refiner_bf16_bytes.restype = C.c_longlong
+        L.sslam_refiner_bf16_bytes.argtypes = [i]
+        L.sslam_refiner_pack_bf16_host.argtypes = [p, i, p]
+        L.sslam_refine_bf16.argtypes = [p, ll, p, i, p, p]
+        L.sslam_gather_refine_bf16.argtypes = [p, i, i, p, i, p, i, p, p]
         L.sslam_vit_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
@@ -145,6 +155,16 @@ def pack_refiner(weights: list, n_blocks: int) -> np.ndarray:
     return out
 
 
+def pack_refiner_bf16(weights: list, n_blocks: int) -> np.ndarray:
+    """bf16-mode image of the same weight list (LayerNorm folded into fc1 / fc2): uint8 buffer."""
+    ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+    assert len(ws) == 4 + 8 * n_blocks
+    out = np.empty(int(lib().sslam_refiner_bf16_bytes(n_blocks)), np.uint8)
+    arr = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    _check(lib().sslam_refiner_pack_bf16_host(arr, n_blocks, out.ctypes.data), "refiner_pack_bf16")
+    return out
+
+
 def resample_table(in_size: int, out_size: int, bicubic: bool):
     bounds = np.empty(out_size * 2, np.int32)
     coefs = np.empty(out_size * MAX_TAPS, np.int32)
@@ -190,6 +210,33 @@ def selector_saliency(feat, w1p, b1, w2, b2, hs, out=None):
     return out
 
 
+def pack_conv3x3_bf16(w: np.ndarray) -> np.ndarray:
+    """-> uint16 array holding the bf16 bit patterns (view it as torch.bfloat16 on the device)."""
+    w = np.ascontiguousarray(w, np.float32)
+    hs = w.shape[0]
+    assert w.shape == (hs, C_FEAT, 3, 3)
+    out = np.empty(9 * C_FEAT * hs, np.uint16)
+    _check(lib().sslam_pack_conv3x3_bf16_host(w.ctypes.data, hs, out.ctypes.data), "pack_conv3x3_bf16")
+    return out
+
+
+def to_bf16(x, out=None):
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _check(lib().sslam_f32_to_bf16(_dp(x), _dp(out), x.numel(), _stream()), "f32_to_bf16")
+    return out
+
+
+def selector_saliency_bf16(feat_bf16, w1p_bf16, b1, w2, b2, hs, out=None):
+    n, g = feat_bf16.shape[0], feat_bf16.shape[1]
+    if out is None:
+        out = torch.empty((n, g, g), dtype=torch.float32, device=feat_bf16.device)
+    _check(lib().sslam_selector_saliency_bf16(_dp(feat_bf16), n, g, _dp(w1p_bf16), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out),
+                                              _stream()), "selector_saliency_bf16")
+    return out
+
+
 def select_keypoints(sal, K, radius=2, pct=0.5, want_idx=True, want_pixel=True):
     n, g = sal.shape[0], sal.shape[1]
     dev = sal.device
@@ -226,6 +273,24 @@ def gather_refine(feat, kp, packed, n_blocks, out=None):
     if out is None:
         out = torch.empty((n, K, D_OUT), dtype=torch.float32, device=feat.device)
     _check(lib().sslam_gather_refine(_dp(feat), n, g, _dp(kp), K, _dp(packed), n_blocks, _dp(out), _stream()), "gather_refine")
+    return out
+
+
+def gather_refine_bf16(feat, kp, packed_bf16, n_blocks, out=None):
+    n, g = feat.shape[0], feat.shape[1]
+    K = kp.shape[1]
+    if out is None:
+        out = torch.empty((n, K, D_OUT), dtype=torch.float32, device=feat.device)
+    _check(lib().sslam_gather_refine_bf16(_dp(feat), n, g, _dp(kp), K, _dp(packed_bf16), n_blocks, _dp(out), _stream()),
+           "gather_refine_bf16")
+    return out
+
+
+def refine_bf16(x, packed_bf16, n_blocks, out=None):
+    rows = x.shape[0]
+    if out is None:
+        out = torch.empty((rows, D_OUT), dtype=torch.float32, device=x.device)
+    _check(lib().sslam_refine_bf16(_dp(x), rows, _dp(packed_bf16), n_blocks, _dp(out), _stream()), "refine_bf16")
     return out
 
 

@@ -38,6 +38,9 @@ class ExtractorConfig:
     use_intensity: bool = True
     spacing: int = 1
     chunk_frames: int = 1024            # frames per launch group; 1024 x 28^2 x 384 fp32 = 1.2 GB of features
+    precision: str = "fp32"             # "fp32": bit-exact vs the CPU reference (the product default and the parity claim);
+                                        # "bf16": BASELINE configs[1] throughput mode - saliency CNN + descriptor MLP on bf16
+                                        # MFMA (fp32 accumulate), everything else unchanged; NOT index-exact
 
     @property
     def grid(self) -> int:
@@ -66,7 +69,7 @@ def refiner_weight_list(sd: dict):
 class PackedSelector:
     """Device-resident, kernel-order copy of a KeypointSelector state_dict."""
 
-    def __init__(self, sd: dict, device):
+    def __init__(self, sd: dict, device, bf16: bool = False):
         w1 = np.ascontiguousarray(_np(sd["conv.0.weight"]), np.float32)
         self.hidden = int(w1.shape[0])
         if self.hidden not in (128, 256) or w1.shape[1:] != (lib.C_FEAT, 3, 3):
@@ -75,16 +78,20 @@ class PackedSelector:
         self.b1 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.0.bias"]), np.float32)).to(device)
         self.w2 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.2.weight"]), np.float32).reshape(-1)).to(device)
         self.b2 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.2.bias"]), np.float32).reshape(-1)).to(device)
+        self.w1p_bf16 = None
+        if bf16:
+            self.w1p_bf16 = torch.from_numpy(lib.pack_conv3x3_bf16(w1)).to(device).view(torch.bfloat16)
 
 
 class PackedRefiner:
     """Device-resident packed DescriptorRefiner weights (one buffer, sslam_refiner_layout order)."""
 
-    def __init__(self, sd: dict, device):
+    def __init__(self, sd: dict, device, bf16: bool = False):
         ws, self.n_blocks = refiner_weight_list(sd)
         if ws[0].shape != (lib.HID, lib.C_FEAT) or ws[-2].shape != (lib.D_OUT, lib.HID):
             raise lib.SslamHipError("refiner shape unsupported by the HIP kernels (384 -> 384 -> 128)")
         self.packed = torch.from_numpy(lib.pack_refiner(ws, self.n_blocks)).to(device)
+        self.packed_bf16 = torch.from_numpy(lib.pack_refiner_bf16(ws, self.n_blocks)).to(device) if bf16 else None
 
 
 class ResampleTables:
@@ -112,8 +119,11 @@ class SequencePipeline:
         self.cfg = cfg
         self.device = torch.device(device)
         lib.lib()   # fail loudly if the HIP library is not built
-        self.selector = PackedSelector(selector_state, self.device)
-        self.refiner = PackedRefiner(refiner_state, self.device)
+        if cfg.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {cfg.precision!r}")
+        self.bf16 = cfg.precision == "bf16"
+        self.selector = PackedSelector(selector_state, self.device, self.bf16)
+        self.refiner = PackedRefiner(refiner_state, self.device, self.bf16)
         c = lib.C_FEAT
         bn = bn_state or {}
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -162,9 +172,15 @@ class SequencePipeline:
         """A2..A9 for a batch of frames.  Returns device tensors; no host synchronisation."""
         cfg, s = self.cfg, self.selector
         feat = self.features(tokens)
-        sal = lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden)
+        if self.bf16:
+            sal = lib.selector_saliency_bf16(lib.to_bf16(feat), s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden)
+        else:
+            sal = lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden)
         kp, sc, idx, px, st = lib.select_keypoints(sal, cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile)
-        desc = lib.gather_refine(feat, kp, self.refiner.packed, self.refiner.n_blocks)
+        if self.bf16:
+            desc = lib.gather_refine_bf16(feat, kp, self.refiner.packed_bf16, self.refiner.n_blocks)
+        else:
+            desc = lib.gather_refine(feat, kp, self.refiner.packed, self.refiner.n_blocks)
         out = dict(saliency=sal, keypoints_patch=kp, keypoints_pixel=px, scores=sc, idx=idx, descriptors=desc, status=st)
         if images_u8 is not None:
             n, h, w, _ = images_u8.shape

@@ -1,0 +1,165 @@
+"""GPU tests of the bf16 THROUGHPUT mode (BASELINE.json configs[1] "bf16 conv stack").
+
+This mode is NOT index-exact against the fp32 reference by construction (operands are rounded to bf16), so the bar is
+different from test_gpu_parity.py and stated here:
+  * kernel correctness: against a numpy restatement that rounds the SAME operands to bf16 (round-to-nearest-even)
+    and accumulates in float64 - what is left is fp32 accumulation-order noise: tolerance 2e-4 on saliency/descriptors;
+  * model-level drift: against the exact fp32 oracle, loose bounds, plus the keypoint / match agreement rates the bench
+    reports (asserted only to be high on the synthetic weights, the rate itself is a measured quantity).
+The exact mode remains the product default and the only one the parity claim is made for.
+"""
+import numpy as np
+import pytest
+
+import synth
+from oracle import ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def hip(T):
+    from sslam_amd import lib
+    lib.lib()
+    return lib
+
+
+def dev(T, a):
+    return T.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bf16_round(a):
+    """float32 -> nearest bf16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def saliency_bf16_ref(feat, sd):
+    """conv3x3 (bf16 operands, float64 accumulate) + ReLU + conv1x1 + sigmoid (keypoint_selector.py:45-67)."""
+    n, g, _, c = feat.shape
+    x = np.zeros((n, g + 2, g + 2, c), np.float64)
+    x[:, 1:-1, 1:-1] = bf16_round(feat)
+    w = bf16_round(sd["conv.0.weight"]).astype(np.float64)          # (hs, c, 3, 3)
+    hid = np.zeros((n, g, g, w.shape[0]), np.float64) + sd["conv.0.bias"].astype(np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            hid += x[:, ky:ky + g, kx:kx + g] @ w[:, :, ky, kx].T
+    hid = np.maximum(hid.astype(np.float32), 0).astype(np.float64)
+    logit = hid @ sd["conv.2.weight"].reshape(-1).astype(np.float64) + float(sd["conv.2.bias"].reshape(-1)[0])
+    return (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+
+
+def test_f32_to_bf16_is_round_to_nearest_even(T, hip):
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal(8 * 1000) * 10.0 ** rng.integers(-6, 6, 8000)).astype(np.float32)
+    a[:8] = [1.00390625, 1.01171875, -1.00390625, 0.0, -0.0, 3.3895314e38, 1e-30, 65280.0]   # exact ties, extremes
+    got = hip.to_bf16(dev(T, a)).float().cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), bf16_round(a).view(np.uint32))
+
+
+@pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (28, 2, 128), (5, 2, 256)])
+def test_selector_saliency_bf16(T, hip, grid, frames, hidden):
+    sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
+    feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
+    w1p = dev(T, hip.pack_conv3x3_bf16(sd["conv.0.weight"])).view(T.bfloat16)
+    fb = hip.to_bf16(dev(T, feat))
+    n0 = hip.launch_count()
+    sal = hip.selector_saliency_bf16(fb, w1p, dev(T, sd["conv.0.bias"]), dev(T, sd["conv.2.weight"].reshape(-1)),
+                                     dev(T, sd["conv.2.bias"]), hidden).cpu().numpy()
+    assert hip.launch_count() == n0 + 1
+    ref = saliency_bf16_ref(feat, sd)
+    assert np.abs(sal - ref).max() < 2e-4, np.abs(sal - ref).max()
+    exact = ora.selector_saliency(feat, sd)
+    assert np.abs(sal - exact).max() < 3e-2, np.abs(sal - exact).max()       # model-level drift of the bf16 mode
+    # deterministic: a second launch gives the same bits
+    sal2 = hip.selector_saliency_bf16(fb, w1p, dev(T, sd["conv.0.bias"]), dev(T, sd["conv.2.weight"].reshape(-1)),
+                                      dev(T, sd["conv.2.bias"]), hidden).cpu().numpy()
+    np.testing.assert_array_equal(sal.view(np.uint32), sal2.view(np.uint32))
+
+
+def refine_bf16_ref(x, sd, n_blocks=2):
+    """The bf16 kernel's formulation in float64: bf16 GEMM operands, LayerNorm folded into the next GEMM
+    (descriptor_refiner.py:58-126 algebraically; refine_bf16.hip header)."""
+    f8 = np.float64
+
+    def lin(a, W, b):
+        return bf16_round(a.astype(np.float32)).astype(f8) @ bf16_round(W).astype(f8).T + b.astype(f8)
+
+    def ln_lin(a, gam, bet, W, b):
+        a32 = a.astype(np.float32).astype(f8)
+        mean = a32.mean(-1, keepdims=True)
+        var = np.maximum((a32 * a32).mean(-1, keepdims=True) - mean * mean, 0)
+        rstd = 1.0 / np.sqrt(var + 1e-5)
+        wg = bf16_round((W * gam[None, :]).astype(np.float32)).astype(f8)
+        c = b.astype(f8) + W.astype(f8) @ bet.astype(f8)
+        return rstd * (bf16_round(a.astype(np.float32)).astype(f8) @ wg.T - mean * wg.sum(1)[None, :]) + c[None, :]
+
+    X = np.maximum(lin(x, sd["input_proj.weight"], sd["input_proj.bias"]), 0)
+    for i in range(n_blocks):
+        p = f"residual_blocks.{i}."
+        h = np.maximum(ln_lin(X, sd[p + "norm1.weight"], sd[p + "norm1.bias"], sd[p + "fc1.weight"], sd[p + "fc1.bias"]), 0)
+        X = np.maximum(ln_lin(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "fc2.weight"], sd[p + "fc2.bias"]) + X, 0)
+    o = lin(X, sd["output_proj.weight"], sd["output_proj.bias"])
+    return (o / np.maximum(np.sqrt((o * o).sum(-1, keepdims=True)), 1e-12)).astype(np.float32)
+
+
+@pytest.mark.parametrize("grid,K,frames", [(28, 500, 3), (40, 1024, 1), (28, 37, 2)])
+def test_gather_refine_bf16(T, hip, grid, K, frames):
+    sd = synth.refiner_state(0)
+    feat = ora.bn_tokens(synth.tokens(30 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
+    sal = ora.selector_saliency(feat, synth.selector_state(0))
+    kp, _, idx, _ = ora.select_keypoints(sal, K)
+    packed = dev(T, hip.pack_refiner_bf16(ora.refiner_weight_list(sd, 2), 2))
+    desc = hip.gather_refine_bf16(dev(T, feat), dev(T, kp), packed, 2).cpu().numpy()
+    x = ora.gather(feat, kp)
+    # the x_in entry point agrees bit-for-bit with the fused gather
+    desc2 = hip.refine_bf16(dev(T, x.reshape(-1, 384)), packed, 2).cpu().numpy().reshape(desc.shape)
+    np.testing.assert_array_equal(desc.view(np.uint32), desc2.view(np.uint32))
+    ref = refine_bf16_ref(x.reshape(-1, 384), sd).reshape(desc.shape)
+    # fp32-vs-float64 accumulation noise is ~1e-8 here; the rare larger differences are activations that sit on a bf16
+    # rounding boundary and round the other way (one flip moves a unit descriptor by ~1e-3)
+    # (~2000 roundings per row: a few percent of the rows see one)
+    d = np.abs(desc - ref)
+    rows_hit = np.mean(d.max(-1) > 1e-5)
+    assert np.median(d) < 1e-7 and rows_hit < 0.15 and d.max() < 5e-3, (np.median(d), rows_hit, d.max())
+    exact = ora.refine(x, sd)
+    cos = (desc * exact).sum(-1)
+    assert cos.min() > 0.999, cos.min()                                      # model-level drift of the bf16 mode
+    assert np.abs(np.sqrt((desc * desc).sum(-1)) - 1).max() < 1e-5
+
+
+def test_pipeline_bf16_mode_agreement(T, hip):
+    """SequencePipeline(precision='bf16') against the exact mode on the same frames: every stage ran on the HIP
+    path, keypoint sets and mutual matches agree to a high (measured, printed) rate."""
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    n = 6
+    toks, imgs = dev(T, synth.token_sequence(n, 28)), dev(T, synth.image_sequence(n))
+    ssd, rsd = synth.selector_state(0), synth.refiner_state(0)
+    ex = SequencePipeline(ExtractorConfig(), ssd, rsd).run(imgs, toks)
+    n0 = hip.launch_count()
+    bf = SequencePipeline(ExtractorConfig(precision="bf16"), ssd, rsd).run(imgs, toks)
+    assert hip.launch_count() - n0 >= 8
+    kp_same = np.mean([len(set(a.tolist()) & set(b.tolist())) / 500.0
+                       for a, b in zip(ex["idx"].cpu().numpy(), bf["idx"].cpu().numpy())])
+    agree = []
+    for p in range(n - 1):
+        ce, cb = int(ex["match_count"][p]), int(bf["match_count"][p])
+        # compare matches as (cell of kp1, cell of kp2) so that a permutation of the keypoint order does not count
+        def cells(o, c):
+            m = o["matches"][p, :c].cpu().numpy()
+            i1, i2 = o["idx"][p].cpu().numpy(), o["idx"][p + 1].cpu().numpy()
+            return set(zip(i1[m[:, 0]].tolist(), i2[m[:, 1]].tolist()))
+        se, sb = cells(ex, ce), cells(bf, cb)
+        agree.append(len(se & sb) / max(len(se), 1))
+    print(f"bf16 mode: keypoint-set agreement {kp_same:.4f}, match agreement {np.mean(agree):.4f}")
+    assert kp_same > 0.9 and np.mean(agree) > 0.8
+    with pytest.raises(ValueError):
+        SequencePipeline(ExtractorConfig(precision="fp8"), ssd, rsd)
