@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +218,38 @@ def main():
                    "vit_gflop_per_frame": round(vit_flop / 1e9, 2), "matches_per_pair": round(float(ov["match_count"].float().mean().item()), 1)}
         del pipe_v, ov
 
+    # additional leg (N = 1): BASELINE configs[1] "bf16 conv stack + fp32 matcher" - the same pass with the saliency CNN and
+    # the descriptor MLP on bf16 MFMA.  Not index-exact, so it is never `value`: reported with its agreement rates against
+    # the exact pass above on the same frames.
+    bf16_leg = None
+    if world == 1 and not args.no_bf16:
+        import dataclasses
+        pipe_b = SequencePipeline(dataclasses.replace(cfg, precision="bf16"), ssd, rsd, device=dev)
+        for _ in range(max(1, args.warmup)):
+            ob = pipe_b.run(imgs, toks, with_preprocess=True)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            ob = pipe_b.run(imgs, toks, with_preprocess=True)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - tb) / args.steps
+        ie, ib = out["idx"].cpu().numpy(), ob["idx"].cpu().numpy()
+        kp_agree = float(np.mean([np.intersect1d(a, b).size / float(K) for a, b in zip(ie, ib)]))
+        me, mb = out["matches"].cpu().numpy(), ob["matches"].cpu().numpy()
+        ce, cb = out["match_count"].cpu().numpy(), ob["match_count"].cpu().numpy()
+        hit = tot = 0
+        for p_ in range(n - 1):     # a match = (cell of keypoint 1, cell of keypoint 2): independent of keypoint order
+            se = set(zip(ie[p_][me[p_, :ce[p_], 0]].tolist(), ie[p_ + 1][me[p_, :ce[p_], 1]].tolist()))
+            sb = set(zip(ib[p_][mb[p_, :cb[p_], 0]].tolist(), ib[p_ + 1][mb[p_, :cb[p_], 1]].tolist()))
+            hit += len(se & sb)
+            tot += len(se)
+        bf16_leg = {"value": round(n / dtb, 2), "unit": "frames/s", "ms_per_step": round(dtb * 1e3, 3), "dtype": "bf16 operands, f32 accumulate",
+                    "what": "A0, A2, A3 (bf16 MFMA), A4/A5, A6+A7 (bf16 MFMA), A9, M1 (fp32): BASELINE configs[1]",
+                    "keypoint_set_agreement_vs_exact": round(kp_agree, 4),
+                    "match_agreement_vs_exact": round(hit / max(tot, 1), 4),
+                    "matches_per_pair": round(float(cb.mean()), 1)}
+        del pipe_b, ob
+
     if rank == 0:
         stage_ms = {k: round(float(np.mean([a.elapsed_time(b) for a, b in v])), 4) for k, v in ev.items()}
         cells = grid * grid
@@ -260,6 +293,8 @@ def main():
         }
         if world == 1 and not args.no_vit:
             res["with_vit"] = vit_leg
+        if bf16_leg is not None:
+            res["bf16_mode"] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
         print(json.dumps(res))

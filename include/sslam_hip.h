@@ -86,6 +86,10 @@ int sslam_selector_saliency(const float *feat, int n_frames, int G, const float 
  * sslam_f32_to_bf16: the bf16 copy of the feature map (n % 8 == 0, 16-byte aligned pointers).
  * sslam_pack_conv3x3_bf16_host: w (hs,384,3,3) fp32 -> 9*384*hs bf16 in MFMA-fragment order. */
 int sslam_f32_to_bf16(const float *in, void *out_bf16, long long n, void *stream);
+/* sslam_bn_tokens that also writes the bf16 copy of out_feat (same shape) in the same pass */
+int sslam_bn_tokens_bf16copy(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                             const float *gamma, const float *beta, const float *run_mean, const float *run_var, int train,
+                             float eps, float *out_feat, void *out_feat_bf16, float *out_mean, float *out_var, void *stream);
 int sslam_pack_conv3x3_bf16_host(const float *w_host, int hs, void *out_bf16_host);
 int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames, int G, const void *w1_packed_bf16, const float *b1,
                                  const float *w2, const float *b2, int hs, float *sal, void *stream);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
                                                          const float *__restrict__ run_mean,
                                                          const float *__restrict__ run_var, int train, float eps,
                                                          float *__restrict__ out_feat, float *__restrict__ out_mean,
-                                                         float *__restrict__ out_var) {
+                                                         float *__restrict__ out_var, uint2 *__restrict__ out_bf16) {
     __shared__ float sh[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, ch0 = blockIdx.y * 64 + 4 * (lane & 15);
@@ -91,26 +91,52 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
         float4 y;
         y.x = x.x * al.x + bs.x; y.y = x.y * al.y + bs.y; y.z = x.z * al.z + bs.z; y.w = x.w * al.w + bs.w;
         *reinterpret_cast<float4 *>(out_feat + (frame0 * cells + r) * SSLAM_C + ch0) = y;
+        if (out_bf16) {   // bf16 copy for the throughput-mode saliency CNN (selector_bf16.hip): 4 values = 8 B per lane
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const f32x2 lo = {y.x, y.y}, hi = {y.z, y.w};
+            uint2 o;
+            o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            out_bf16[((frame0 * cells + r) * SSLAM_C + ch0) / 4] = o;
+        }
     }
 }
 
 }  // namespace
 
-extern "C" int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
-                               const float *gamma, const float *beta, const float *run_mean, const float *run_var,
-                               int train, float eps, float *out_feat, float *out_mean, float *out_var, void *stream) {
+static int bn_launch(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                     const float *gamma, const float *beta, const float *run_mean, const float *run_var,
+                     int train, float eps, float *out_feat, float *out_mean, float *out_var, void *out_bf16, void *stream) {
     if (!tokens || !gamma || !beta || !out_feat || n_frames <= 0 || group <= 0 || n_prefix < 0 ||
         tokens_per_frame <= n_prefix)
         return SSLAM_E_INVALID;
     if (!train && (!run_mean || !run_var)) return SSLAM_E_INVALID;
     if (n_frames % group) return SSLAM_E_INVALID;
     if (((uintptr_t)tokens | (uintptr_t)out_feat | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)run_mean |
-         (uintptr_t)run_var | (uintptr_t)out_mean | (uintptr_t)out_var) & 15)
+         (uintptr_t)run_var | (uintptr_t)out_mean | (uintptr_t)out_var | (uintptr_t)out_bf16) & 15)
         return SSLAM_E_INVALID;
     if ((long long)group * (tokens_per_frame - n_prefix) > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_tokens_kernel, dim3(n_frames / group, SSLAM_C / 64), dim3(256), 0, (hipStream_t)stream, tokens,
                        tokens_per_frame, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out_feat,
-                       out_mean, out_var);
+                       out_mean, out_var, (uint2 *)out_bf16);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
+}
+
+extern "C" int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                               const float *gamma, const float *beta, const float *run_mean, const float *run_var,
+                               int train, float eps, float *out_feat, float *out_mean, float *out_var, void *stream) {
+    return bn_launch(tokens, n_frames, tokens_per_frame, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out_feat,
+                     out_mean, out_var, nullptr, stream);
+}
+
+// the same kernel, additionally writing the bf16 (round-to-nearest-even) copy of out_feat that the bf16-mode saliency CNN reads
+extern "C" int sslam_bn_tokens_bf16copy(const float *tokens, int n_frames, int tokens_per_frame, int n_prefix, int group,
+                                        const float *gamma, const float *beta, const float *run_mean, const float *run_var,
+                                        int train, float eps, float *out_feat, void *out_feat_bf16, float *out_mean,
+                                        float *out_var, void *stream) {
+    if (!out_feat_bf16) return SSLAM_E_INVALID;
+    return bn_launch(tokens, n_frames, tokens_per_frame, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out_feat,
+                     out_mean, out_var, out_feat_bf16, stream);
 }

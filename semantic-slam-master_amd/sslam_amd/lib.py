@@ -61,7 +61,7 @@ EXPORTS = [
     "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
     "sslam_vit_workspace_bytes", "sslam_vit_forward",
     "sslam_f32_to_bf16", "sslam_pack_conv3x3_bf16_host", "sslam_selector_saliency_bf16",
-    "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
+    "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.sslam_f32_to_bf16.argtypes = [p, p, ll, p]
         L.sslam_pack_conv3x3_bf16_host.argtypes = [p, i, p]
         L.sslam_selector_saliency_bf16.argtypes = [p, i, i, p, p, p, p, i, p, p]
+        L.sslam_bn_tokens_bf16copy.argtypes = [p, i, i, i, i, p, p, p, p, i, f, p, p, p, p, p]
         L.sslam_refiner_bf16_bytes.restype = C.c_longlong
         L.sslam_refiner_bf16_bytes.argtypes = [i]
         L.sslam_refiner_pack_bf16_host.argtypes = [p, i, p]
@@ -186,7 +187,8 @@ def preprocess_u8(img, size, tab_h, tab_v, out=None):
     return out
 
 
-def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out=None, want_stats=True):
+def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out=None, want_stats=True, bf16_copy=False):
+    """bf16_copy=True: returns (out, mean, var, out_bf16) - the bf16 copy is written by the same kernel pass."""
     n, t, c = tokens.shape
     assert c == C_FEAT and tokens.dtype == torch.float32
     cells = t - n_prefix
@@ -196,6 +198,12 @@ def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, ep
     if train and want_stats:
         mean = torch.empty((n // group, c), dtype=torch.float32, device=tokens.device)
         var = torch.empty_like(mean)
+    if bf16_copy:
+        out_bf = torch.empty((n, cells, c), dtype=torch.bfloat16, device=tokens.device)
+        _check(lib().sslam_bn_tokens_bf16copy(_dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean),
+                                              _dp(run_var), int(bool(train)), C.c_float(eps), _dp(out), _dp(out_bf), _dp(mean),
+                                              _dp(var), _stream()), "bn_tokens_bf16copy")
+        return out, mean, var, out_bf
     _check(lib().sslam_bn_tokens(_dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean), _dp(run_var),
                                  int(bool(train)), C.c_float(eps), _dp(out), _dp(mean), _dp(var), _stream()), "bn_tokens")
     return out, mean, var

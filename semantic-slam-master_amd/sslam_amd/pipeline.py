@@ -159,22 +159,26 @@ class SequencePipeline:
             self.vit_hip.forward_features(x, out=out[a:b])
         return out
 
-    def features(self, tokens: torch.Tensor) -> torch.Tensor:
-        """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features."""
+    def features(self, tokens: torch.Tensor, bf16_copy: bool = False):
+        """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features
+        (bf16_copy: also their bf16 copy, written in the same pass, for the bf16-mode saliency CNN)."""
         g = self.cfg.grid
         if tokens.shape[1] != N_PREFIX + g * g:
             raise AssertionError(f"Expected {g * g} patches, got {tokens.shape[1] - N_PREFIX}")   # dino_backbone.py:94
-        feat, _, _ = lib.bn_tokens(tokens, N_PREFIX, 1, self.bn_gamma, self.bn_beta, self.bn_mean, self.bn_var,
-                                   self.cfg.bn_train_mode, self.cfg.bn_eps, want_stats=False)
-        return feat.view(tokens.shape[0], g, g, lib.C_FEAT)
+        r = lib.bn_tokens(tokens, N_PREFIX, 1, self.bn_gamma, self.bn_beta, self.bn_mean, self.bn_var,
+                          self.cfg.bn_train_mode, self.cfg.bn_eps, want_stats=False, bf16_copy=bf16_copy)
+        shape = (tokens.shape[0], g, g, lib.C_FEAT)
+        return (r[0].view(shape), r[3].view(shape)) if bf16_copy else r[0].view(shape)
 
     def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
         """A2..A9 for a batch of frames.  Returns device tensors; no host synchronisation."""
         cfg, s = self.cfg, self.selector
-        feat = self.features(tokens)
         if self.bf16:
-            sal = lib.selector_saliency_bf16(lib.to_bf16(feat), s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden)
+            feat, feat_bf = self.features(tokens, bf16_copy=True)
+            sal = lib.selector_saliency_bf16(feat_bf, s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden)
+            del feat_bf
         else:
+            feat = self.features(tokens)
             sal = lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden)
         kp, sc, idx, px, st = lib.select_keypoints(sal, cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile)
         if self.bf16:

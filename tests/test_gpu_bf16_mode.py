@@ -65,6 +65,15 @@ def test_f32_to_bf16_is_round_to_nearest_even(T, hip):
     np.testing.assert_array_equal(got.view(np.uint32), bf16_round(a).view(np.uint32))
 
 
+def test_bn_tokens_bf16_copy(T, hip):
+    toks = synth.tokens(11, 28, 3)
+    ones, zeros = dev(T, np.ones(384, np.float32)), dev(T, np.zeros(384, np.float32))
+    feat, _, _, fb = hip.bn_tokens(dev(T, toks), 5, 1, ones, zeros, zeros, ones, True, 1e-5, bf16_copy=True)
+    want = ora.bn_tokens(toks)[0]
+    np.testing.assert_array_equal(feat.cpu().numpy().view(np.uint32), want.view(np.uint32))          # fp32 output unchanged
+    np.testing.assert_array_equal(fb.float().cpu().numpy().view(np.uint32), bf16_round(want).view(np.uint32))
+
+
 @pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (28, 2, 128), (5, 2, 256)])
 def test_selector_saliency_bf16(T, hip, grid, frames, hidden):
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
@@ -146,7 +155,7 @@ def test_pipeline_bf16_mode_agreement(T, hip):
     ex = SequencePipeline(ExtractorConfig(), ssd, rsd).run(imgs, toks)
     n0 = hip.launch_count()
     bf = SequencePipeline(ExtractorConfig(precision="bf16"), ssd, rsd).run(imgs, toks)
-    assert hip.launch_count() - n0 >= 8
+    assert hip.launch_count() - n0 >= 7
     kp_same = np.mean([len(set(a.tolist()) & set(b.tolist())) / 500.0
                        for a, b in zip(ex["idx"].cpu().numpy(), bf["idx"].cpu().numpy())])
     agree = []
