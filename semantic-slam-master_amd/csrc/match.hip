@@ -51,11 +51,26 @@ struct Stager {
     }
 };
 
+// monotone 64-bit image of (similarity, query index): "larger value, then lower index" is one unsigned compare, so the
+// column direction can be reduced with max() in any order (lanes, waves, workgroups) and still give the first maximum
+__device__ __forceinline__ unsigned long long sim_key(float v, int i) {
+    unsigned u = __float_as_uint(v + 0.0f);                 // -0 -> +0: equal under the float compare of the reference
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    return ((unsigned long long)u << 32) | (unsigned)(~i);
+}
+
+// ONEPASS = false: grid (query blocks, 2 directions, pairs) - S is evaluated once per direction, nothing but the outputs
+//                  is written (single pairs / small batches: twice the workgroups to spread over the CUs).
+// ONEPASS = true:  grid (query blocks, 1, pairs) - S is evaluated ONCE; the column direction (nn21) is reduced over the
+//                  32 query lanes of each half-wave by a reduce-scatter butterfly on sim_key()s and merged across waves
+//                  and workgroups with a 64-bit atomic max into `keys` (n_pairs x n2, zeroed), decoded by keys_decode_kernel.
+template <bool ONEPASS>
 __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
                                                           const float *__restrict__ desc2, long long stride2, int n2,
                                                           int *__restrict__ nn12, float *__restrict__ s12,
                                                           int *__restrict__ nn21, float *__restrict__ s21,
-                                                          float *__restrict__ second12) {
+                                                          float *__restrict__ second12,
+                                                          unsigned long long *__restrict__ keys) {
     __shared__ __attribute__((aligned(16))) float smem[(QB + 2 * CB) * LDD];
     float *Qs = smem, *Cs = smem + QB * LDD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -100,18 +115,45 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
         }
         const int jbase = s * CB + wc * 32;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int j = jbase + crow(e, h);
-            if (j < nc) {
-                const float v = acc[e];
-                if (v > best) {
-                    second = best;
-                    best = v;
-                    besti = j;
-                } else if (v > second) {
-                    second = v;
+        for (int e = 0; e < 16; e++) {   // branch-free form of: if (v > best) {second = best; best = v; besti = j;}
+            const int j = jbase + crow(e, h);  //                  else if (v > second) second = v;      (rows j >= nc skipped)
+            const float v = j < nc ? acc[e] : -INFINITY;
+            const bool gt = v > best;
+            second = gt ? best : fmaxf(second, v);
+            besti = gt ? j : besti;
+            best = gt ? v : best;
+        }
+        if (ONEPASS) {
+            const int qi = q0 + wq * 32 + r;
+            const bool qok = qi < nq;
+            unsigned long long k[8];
+            {
+                const bool up = (r & 16) != 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    unsigned long long lo = qok ? sim_key(acc[i], qi) : 0ull, hi = qok ? sim_key(acc[i + 8], qi) : 0ull;
+                    asm volatile("" : "+v"(lo), "+v"(hi));      // keeps the selects from being folded into a dynamic vector index
+                    const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
+                    const unsigned long long o = __shfl_xor(send, 16);
+                    k[i] = keep > o ? keep : o;
                 }
             }
+#pragma unroll
+            for (int m = 4; m >= 1; m >>= 1) {
+                const bool up = (r & (2 * m)) != 0;
+#pragma unroll
+                for (int i = 0; i < m; i++) {
+                    unsigned long long lo = k[i], hi = k[i + m];
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
+                    const unsigned long long o = __shfl_xor(send, 2 * m);
+                    k[i] = keep > o ? keep : o;
+                }
+            }
+            const unsigned long long o = __shfl_xor(k[0], 1);
+            const unsigned long long kk = k[0] > o ? k[0] : o;
+            const int j = jbase + crow((r >> 1) & 15, h);       // the accumulator row this lane pair ended up holding
+            if (!(r & 1) && j < nc) atomicMax(keys + pair * n2 + j, kk);
         }
         if (s + 1 < nstage) sc.store(Cs + ((s + 1) & 1) * CB * LDD, tid);
         __syncthreads();
@@ -153,6 +195,17 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
         if (o_val) o_val[q0 + tid] = v;
         if (o_sec) o_sec[q0 + tid] = sc;
     }
+}
+
+__global__ __launch_bounds__(256) void keys_decode_kernel(const unsigned long long *__restrict__ keys, long long n,
+                                                           int *__restrict__ nn21, float *__restrict__ s21) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long kk = keys[i];
+    unsigned u = (unsigned)(kk >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+    nn21[i] = (int)(~(unsigned)kk);
+    if (s21) s21[i] = __uint_as_float(u);
 }
 
 // one workgroup per pair: mutual check, thresholds, quality, ordered compaction (ascending idx1)
@@ -224,9 +277,27 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
     if (!desc1 || !desc2 || !nn12 || !nn21 || n1 <= 0 || n2 <= 0 || n_pairs <= 0) return SSLAM_E_INVALID;
     if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15 || (stride1 & 3) || (stride2 & 3)) return SSLAM_E_INVALID;
     if (n_pairs > 65535) return SSLAM_E_UNSUPPORTED;
+    // variant: 0 = by batch size, 1 = S per direction (no scratch memory), 2 = S once + 64-bit key reduction
+    const char *env = getenv("SSLAM_M1_VARIANT");
+    const int forced = env ? atoi(env) : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (forced == 2 || (forced == 0 && n_pairs >= 16)) {
+        unsigned long long *keys = nullptr;
+        const size_t bytes = (size_t)n_pairs * n2 * sizeof(unsigned long long);
+        if (hipMallocAsync((void **)&keys, bytes, st) != hipSuccess) return SSLAM_E_LAUNCH;   // stream-ordered scratch
+        if (hipMemsetAsync(keys, 0, bytes, st) != hipSuccess) return SSLAM_E_LAUNCH;
+        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
+                           desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys);
+        SSLAM_CHECK_LAUNCH();
+        const long long n = (long long)n_pairs * n2;
+        hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
+        SSLAM_CHECK_LAUNCH();
+        if (hipFreeAsync(keys, st) != hipSuccess) return SSLAM_E_LAUNCH;
+        return SSLAM_OK;
+    }
     const int nmax = n1 > n2 ? n1 : n2;
-    hipLaunchKernelGGL(sim_argmax_kernel, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(512), 0, (hipStream_t)stream, desc1,
-                       stride1, n1, desc2, stride2, n2, nn12, s12, nn21, s21, second12);
+    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
+                       desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }

@@ -263,6 +263,27 @@ def test_batched_pairs_and_strides(T, hip):
         assert_bits(q.cpu().numpy()[p, :c], oq, f"pair {p}")
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("n,m,dup", [(500, 500, 40), (33, 70, 5), (700, 129, 60), (128, 1, 0), (1, 300, 0), (1024, 1000, 100)])
+def test_sim_argmax_both_forms(T, hip, variant, n, m, dup, monkeypatch):
+    """SSLAM_M1_VARIANT=1: S per direction; =2: S once + 64-bit key reduction for the column direction (the form batched
+    calls use).  Both must give the oracle's first-maximum indices (duplicated descriptors = exact ties) and values."""
+    monkeypatch.setenv("SSLAM_M1_VARIANT", variant)
+    d1, d2, *_ = _pair(900 + n + m, n, m, dup)
+    pairs = 3
+    D1 = dev(T, np.stack([d1, d1[::-1], d1]))
+    D2 = dev(T, np.stack([d2, d2, d2[::-1]]))
+    nn12, s12, nn21, s21, sec = hip.sim_argmax(D1, n * 128, n, D2, m * 128, m, pairs, want_s21=True, want_second=True)
+    for p, (a, b) in enumerate([(d1, d2), (d1[::-1], d2), (d1, d2[::-1])]):
+        o12, os12, o21, os21 = ora.sim_argmax(np.ascontiguousarray(a), np.ascontiguousarray(b))
+        assert np.array_equal(nn12.cpu().numpy()[p], o12) and np.array_equal(nn21.cpu().numpy()[p], o21), (variant, p)
+        assert_bits(s12.cpu().numpy()[p], os12, "s12")
+        assert_bits(s21.cpu().numpy()[p], os21, "s21")
+        S = ora.sim_matrix(np.ascontiguousarray(a), np.ascontiguousarray(b))
+        S[np.arange(n), o12] = -np.inf
+        assert_bits(sec.cpu().numpy()[p], S.max(1), "second12")
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 def test_end_to_end_golden(T, hip):
     """tokens + images -> keypoints, descriptors, intensity, matches: indices / pairs equal the reference's."""
