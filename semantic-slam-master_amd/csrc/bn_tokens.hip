@@ -10,6 +10,8 @@
 
 namespace {
 
+constexpr int U = 7;   // rows in flight per lane (784 cells = 16 lanes-rows x 49 = 7 x 7)
+
 __device__ __forceinline__ float4 comb16(float4 v, float (*sh)[64], int wave, int lane) {
     // v: this lane's partial P[4*wave + (lane>>4)] for 4 channels
     float4 s;
@@ -54,20 +56,32 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
 
     float4 mean, var;
     if (train) {
+        // the sweeps are latency-bound unless several rows are in flight per lane: U loads are issued together, then
+        // consumed in row order (the canonical sequential sum of oracle ora_bn_tokens is unchanged)
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = p; r < R; r += 16) {
-            const float4 x = *src(r);
-            s.x = s.x + x.x; s.y = s.y + x.y; s.z = s.z + x.z; s.w = s.w + x.w;
+        for (int r = p; r < R; r += 16 * U) {
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = *src(min(r + 16 * u, R - 1));
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (r + 16 * u < R) { s.x = s.x + x[u].x; s.y = s.y + x[u].y; s.z = s.z + x[u].z; s.w = s.w + x[u].w; }
         }
         const float4 tot = comb16(s, sh, wave, lane);
         const float fr = (float)R;
         mean = make_float4(tot.x / fr, tot.y / fr, tot.z / fr, tot.w / fr);
         s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = p; r < R; r += 16) {
-            const float4 x = *src(r);
-            const float dx = x.x - mean.x, dy = x.y - mean.y, dz = x.z - mean.z, dw = x.w - mean.w;
-            s.x = __builtin_fmaf(dx, dx, s.x); s.y = __builtin_fmaf(dy, dy, s.y);
-            s.z = __builtin_fmaf(dz, dz, s.z); s.w = __builtin_fmaf(dw, dw, s.w);
+        for (int r = p; r < R; r += 16 * U) {
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = *src(min(r + 16 * u, R - 1));
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (r + 16 * u < R) {
+                    const float dx = x[u].x - mean.x, dy = x[u].y - mean.y, dz = x[u].z - mean.z, dw = x[u].w - mean.w;
+                    s.x = __builtin_fmaf(dx, dx, s.x); s.y = __builtin_fmaf(dy, dy, s.y);
+                    s.z = __builtin_fmaf(dz, dz, s.z); s.w = __builtin_fmaf(dw, dw, s.w);
+                }
         }
         const float4 tot2 = comb16(s, sh, wave, lane);
         var = make_float4(tot2.x / fr, tot2.y / fr, tot2.z / fr, tot2.w / fr);
@@ -86,8 +100,15 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
     al.z = (1.0f / sqrtf(var.z + eps)) * ga.z; al.w = (1.0f / sqrtf(var.w + eps)) * ga.w;
     bs.x = be.x - mean.x * al.x; bs.y = be.y - mean.y * al.y;
     bs.z = be.z - mean.z * al.z; bs.w = be.w - mean.w * al.w;
-    for (int r = p; r < R; r += 16) {
-        const float4 x = *src(r);
+    for (int r0 = p; r0 < R; r0 += 16 * U) {
+        float4 xs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xs[u] = *src(min(r0 + 16 * u, R - 1));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+        const int r = r0 + 16 * u;
+        if (r >= R) break;
+        const float4 x = xs[u];
         float4 y;
         y.x = x.x * al.x + bs.x; y.y = x.y * al.y + bs.y; y.z = x.z * al.z + bs.z; y.w = x.w * al.w + bs.w;
         *reinterpret_cast<float4 *>(out_feat + (frame0 * cells + r) * SSLAM_C + ch0) = y;
@@ -100,7 +121,81 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
             o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
             out_bf16[((frame0 * cells + r) * SSLAM_C + ch0) / 4] = o;
         }
+        }
     }
+}
+
+// Register-resident form for group == 1 and cells <= 16 * NR (G = 28: 784 cells = 16 x 49): the three sweeps of the
+// kernel above re-read the tokens from MALL/HBM (a CU's resident workgroups cover far more than its L2 share), which
+// makes that kernel bandwidth-bound at 3x the compulsory read traffic.  Here every lane keeps its NR rows (float4 each)
+// in VGPRs between the sweeps: one HBM read, one write.  Same partition and summation order, bit-identical results.
+// Addresses are one uniform base per row step plus a 32-bit lane offset (no per-row address registers).
+template <int NR>
+__global__ __launch_bounds__(256, 2) void bn_tokens_reg_kernel(const float *__restrict__ tokens, int tokens_per_frame,
+                                                                int n_prefix, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float eps,
+                                                                float *__restrict__ out_feat, float *__restrict__ out_mean,
+                                                                float *__restrict__ out_var, uint2 *__restrict__ out_bf16) {
+    __shared__ float sh[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, ch0 = blockIdx.y * 64 + 4 * (lane & 15);
+    const int R = tokens_per_frame - n_prefix;
+    const int p = 4 * wave + (lane >> 4);
+    const int full = R / 16, rem = R % 16;          // row steps valid for every lane / lanes valid in step `full`
+    const float *src = tokens + ((long long)g * tokens_per_frame + n_prefix) * SSLAM_C;     // uniform
+    const unsigned loff = (unsigned)(p * SSLAM_C + ch0);                                    // per lane, floats
+    float4 x[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < full || (i == full && p < rem)) x[i] = *reinterpret_cast<const float4 *>(src + (size_t)i * 16 * SSLAM_C + loff);
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        if (i < full || (i == full && p < rem)) { s.x = s.x + x[i].x; s.y = s.y + x[i].y; s.z = s.z + x[i].z; s.w = s.w + x[i].w; }
+    const float4 tot = comb16(s, sh, wave, lane);
+    const float fr = (float)R;
+    const float4 mean = make_float4(tot.x / fr, tot.y / fr, tot.z / fr, tot.w / fr);
+    s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        if (i < full || (i == full && p < rem)) {
+            const float dx = x[i].x - mean.x, dy = x[i].y - mean.y, dz = x[i].z - mean.z, dw = x[i].w - mean.w;
+            s.x = __builtin_fmaf(dx, dx, s.x); s.y = __builtin_fmaf(dy, dy, s.y);
+            s.z = __builtin_fmaf(dz, dz, s.z); s.w = __builtin_fmaf(dw, dw, s.w);
+        }
+    const float4 tot2 = comb16(s, sh, wave, lane);
+    const float4 var = make_float4(tot2.x / fr, tot2.y / fr, tot2.z / fr, tot2.w / fr);
+    if (tid < 16) {
+        if (out_mean) *reinterpret_cast<float4 *>(out_mean + (long long)g * SSLAM_C + ch0) = mean;
+        if (out_var) *reinterpret_cast<float4 *>(out_var + (long long)g * SSLAM_C + ch0) = var;
+    }
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + ch0);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + ch0);
+    float4 al, bs;
+    al.x = (1.0f / sqrtf(var.x + eps)) * ga.x; al.y = (1.0f / sqrtf(var.y + eps)) * ga.y;
+    al.z = (1.0f / sqrtf(var.z + eps)) * ga.z; al.w = (1.0f / sqrtf(var.w + eps)) * ga.w;
+    bs.x = be.x - mean.x * al.x; bs.y = be.y - mean.y * al.y;
+    bs.z = be.z - mean.z * al.z; bs.w = be.w - mean.w * al.w;
+    float *dst = out_feat + (long long)g * R * SSLAM_C;                                      // uniform
+    uint2 *dst_bf = out_bf16 ? out_bf16 + (long long)g * R * (SSLAM_C / 4) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        if (i < full || (i == full && p < rem)) {
+            float4 y;
+            y.x = x[i].x * al.x + bs.x; y.y = x[i].y * al.y + bs.y; y.z = x[i].z * al.z + bs.z; y.w = x[i].w * al.w + bs.w;
+            *reinterpret_cast<float4 *>(dst + (size_t)i * 16 * SSLAM_C + loff) = y;
+            if (dst_bf) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const f32x2 lo = {y.x, y.y}, hi = {y.z, y.w};
+                uint2 o;
+                o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+                o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+                dst_bf[(size_t)i * 16 * (SSLAM_C / 4) + loff / 4] = o;
+            }
+        }
 }
 
 }  // namespace
@@ -117,6 +212,12 @@ static int bn_launch(const float *tokens, int n_frames, int tokens_per_frame, in
          (uintptr_t)run_var | (uintptr_t)out_mean | (uintptr_t)out_var | (uintptr_t)out_bf16) & 15)
         return SSLAM_E_INVALID;
     if ((long long)group * (tokens_per_frame - n_prefix) > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    if (train && group == 1 && tokens_per_frame - n_prefix <= 16 * 49) {
+        hipLaunchKernelGGL(bn_tokens_reg_kernel<49>, dim3(n_frames, SSLAM_C / 64), dim3(256), 0, (hipStream_t)stream, tokens,
+                           tokens_per_frame, n_prefix, gamma, beta, eps, out_feat, out_mean, out_var, (uint2 *)out_bf16);
+        SSLAM_CHECK_LAUNCH();
+        return SSLAM_OK;
+    }
     hipLaunchKernelGGL(bn_tokens_kernel, dim3(n_frames / group, SSLAM_C / 64), dim3(256), 0, (hipStream_t)stream, tokens,
                        tokens_per_frame, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out_feat,
                        out_mean, out_var, (uint2 *)out_bf16);

@@ -80,16 +80,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 //  - the <= 21 source bytes of a pixel are fetched as six aligned dwords and re-aligned with v_alignbyte
 //    (byte loads made the first version of this kernel TA-instruction bound at 1.36 TB/s);
 //  - the uint8 intermediate row is kept packed (R | G<<8 | B<<16) so the vertical pass reads one dword per tap.
+//  - TAPS (3, 5 or 7) is the compile-time tap count: 640 -> 448 bilinear needs 5, so two of seven tap slots would be zeros.
+template <int TAPS, int TYT, int MAXRT>
 __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
                                                                const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
                                                                const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
                                                                float *__restrict__ out) {
-    __shared__ unsigned tmp[MAXR][TX];
+    __shared__ unsigned tmp[MAXRT][TX];
     __shared__ float lut[3][256];
     const int tid = threadIdx.x;
     const long long f = blockIdx.z;
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int ty1 = min(y0 + TY, size) - 1;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TYT;
+    const int ty1 = min(y0 + TYT, size) - 1;
     const int rmin = bv[2 * y0], rmax = bv[2 * ty1] + bv[2 * ty1 + 1];   // input rows [rmin, rmax)
     const int nrows = rmax - rmin;
     const long long total_bytes = (long long)gridDim.z * h * w * 3;
@@ -103,50 +105,64 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__r
     const int ox = min(x0 + xx, size - 1);
     {
         const int xmin = bh[2 * ox], xn = bh[2 * ox + 1];
-        int kh[7];
+        constexpr int NW = (3 * TAPS + 3 + 3) / 4;                          // dwords covering 3*TAPS bytes at any alignment
+        int kh[TAPS];
 #pragma unroll
-        for (int t = 0; t < 7; t++) kh[t] = t < xn ? ch[(long long)ox * ksh + t] : 0;
-        for (int rr = q; rr < nrows; rr += 4) {
-            const long long b0 = frame0 + ((long long)(rmin + rr) * w + xmin) * 3;
-            const long long a0 = b0 & ~3LL;
-            const int sh = (int)(b0 & 3);
-            unsigned wds[6];
+        for (int t = 0; t < TAPS; t++) kh[t] = t < xn ? ch[(long long)ox * ksh + t] : 0;
+        // RB rows are fetched together (the pass is load-latency bound otherwise), then filtered one after the other
+        constexpr int RB = 3;
+        for (int rr0 = q; rr0 < nrows; rr0 += 4 * RB) {
+            unsigned wds[RB][NW];
+            int shv[RB];
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const long long a = a0 + 4 * j;
-                unsigned v = 0;
-                if (a + 4 <= total_bytes) {
-                    v = *reinterpret_cast<const unsigned *>(img + a);
-                } else {
-                    for (int k = 0; k < 4; k++)
-                        if (a + k < total_bytes) v |= (unsigned)img[a + k] << (8 * k);
+            for (int i = 0; i < RB; i++) {
+                const int rr = min(rr0 + 4 * i, nrows - 1);
+                const long long b0 = frame0 + ((long long)(rmin + rr) * w + xmin) * 3;
+                const long long a0 = b0 & ~3LL;
+                shv[i] = (int)(b0 & 3);
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    const long long a = a0 + 4 * j;
+                    unsigned v = 0;
+                    if (a + 4 <= total_bytes) {
+                        v = *reinterpret_cast<const unsigned *>(img + a);
+                    } else {
+                        for (int k = 0; k < 4; k++)
+                            if (a + k < total_bytes) v |= (unsigned)img[a + k] << (8 * k);
+                    }
+                    wds[i][j] = v;
                 }
-                wds[j] = v;
             }
-            unsigned al[6];                                                  // bytes b0.. in order
 #pragma unroll
-            for (int j = 0; j < 5; j++) al[j] = __builtin_amdgcn_alignbyte(wds[j + 1], wds[j], sh);
-            al[5] = wds[5] >> (8 * sh);
-            int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+            for (int i = 0; i < RB; i++) {
+                const int rr = rr0 + 4 * i;
+                if (rr >= nrows) break;
+                const int sh = shv[i];
+                unsigned al[NW];                                             // bytes b0.. in order
 #pragma unroll
-            for (int t = 0; t < 7; t++) {
-                const int o = 3 * t;
-                const int r8 = (al[o >> 2] >> (8 * (o & 3))) & 255;
-                const int g8 = (al[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255;
-                const int b8 = (al[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255;
-                s0 += r8 * kh[t];
-                s1 += g8 * kh[t];
-                s2 += b8 * kh[t];
+                for (int j = 0; j < NW - 1; j++) al[j] = __builtin_amdgcn_alignbyte(wds[i][j + 1], wds[i][j], sh);
+                al[NW - 1] = wds[i][NW - 1] >> (8 * sh);
+                int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int t = 0; t < TAPS; t++) {
+                    const int o = 3 * t;
+                    const int r8 = (al[o >> 2] >> (8 * (o & 3))) & 255;
+                    const int g8 = (al[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255;
+                    const int b8 = (al[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255;
+                    s0 += r8 * kh[t];
+                    s1 += g8 * kh[t];
+                    s2 += b8 * kh[t];
+                }
+                tmp[rr][xx] = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16);
             }
-            tmp[rr][xx] = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16);
         }
     }
     __syncthreads();
     const long long plane = (long long)size * size;
     if (x0 + xx < size) {
 #pragma unroll
-        for (int j = 0; j < TY / 4; j++) {
-            const int oy = y0 + q * (TY / 4) + j;
+        for (int j = 0; j < TYT / 4; j++) {
+            const int oy = y0 + q * (TYT / 4) + j;
             if (oy < size) {
                 const int ymin = bv[2 * oy] - rmin, yn = bv[2 * oy + 1];
                 const int *k = cv + (long long)oy * ksv;
@@ -266,12 +282,28 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
     if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
     if (n > 65535) return SSLAM_E_UNSUPPORTED;
     const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, n);
-    if (ksize_h <= 7 && !((uintptr_t)img & 3))
-        hipLaunchKernelGGL(preprocess_fast_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h,
-                           ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+    // the fast kernel prefers 32-row tiles (less vertical-halo re-filtering) when their input rows fit its LDS buffer
+    const bool tall = (32LL * h + size - 1) / size + ksize_v + 2 <= 64;
+    const dim3 grid32((size + TX - 1) / TX, (size + 31) / 32, n);
+#define FAST(T)                                                                                                        \
+    {                                                                                                                  \
+        if (tall)                                                                                                      \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, 32, 64>), grid32, dim3(256), 0, (hipStream_t)stream, img, h, w, size, \
+                               bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, TY, MAXR>), grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, \
+                               bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);                       \
+    }
+    if (ksize_h <= 3 && !((uintptr_t)img & 3))
+        FAST(3)
+    else if (ksize_h <= 5 && !((uintptr_t)img & 3))
+        FAST(5)
+    else if (ksize_h <= 7 && !((uintptr_t)img & 3))
+        FAST(7)
     else
         hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h,
                            ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+#undef FAST
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }

@@ -68,7 +68,7 @@ def test_mfma_chain_is_fmaf_chain(T, hip):
 
 # --------------------------------------------------------------------------------------------------------- A2
 @pytest.mark.parametrize("grid,batch,group,train", [(28, 2, 1, True), (28, 2, 2, True), (28, 2, 1, False), (40, 1, 1, True),
-                                                    (60, 3, 3, True)])
+                                                    (60, 3, 3, True), (27, 3, 1, True), (7, 4, 1, True), (3, 2, 1, True)])
 def test_bn_tokens(T, hip, grid, batch, group, train):
     tok = synth.tokens(10 + grid, grid, batch)
     rng = np.random.Generator(np.random.PCG64(grid))
