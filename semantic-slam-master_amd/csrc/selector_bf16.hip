@@ -22,14 +22,16 @@ constexpr int NSTB = 9 * (SSLAM_C / BKB);
 constexpr int KSB = BKB / 16;            // MFMA k-steps per stage
 constexpr int RING = 4;
 
-template <int WM, int WN>
-__global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
-                                                             const bf16 *__restrict__ w1p, const float *__restrict__ b1,
-                                                             const float *__restrict__ w2, const float *__restrict__ b2,
-                                                             float *__restrict__ sal, int n_tiles) {
-    static_assert(WM * WN == 8, "8 waves");
-    constexpr int BM = 64 * WM, HS = 64 * WN, NSLAB = HS / 64;
-    constexpr int A_ITEMS = BM * (BKB / 8) / 512;          // 16-B pieces per thread per stage
+// WM x WN waves; each wave owns MI x 2 accumulator tiles (32*MI rows x 64 columns).  MI = 4 halves the B-fragment
+// traffic per MFMA (the L1 path of the direct B loads is what bounds the MI = 2 form).
+template <int WM, int WN, int MI>
+__global__ __launch_bounds__(64 * WM * WN) void selector_bf16_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
+                                                                     const bf16 *__restrict__ w1p, const float *__restrict__ b1,
+                                                                     const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                     float *__restrict__ sal, int n_tiles) {
+    constexpr int NTH = 64 * WM * WN, BM = 32 * MI * WM, HS = 64 * WN, NSLAB = HS / 64;
+    constexpr int A_ITEMS = BM * (BKB / 8) / NTH;          // 16-B pieces per thread per stage
+    constexpr int ROWSTEP = NTH / (BKB / 8);               // rows between a thread's consecutive pieces
     constexpr int STAGE = BM * LDB;
     constexpr int SMEM = 2 * STAGE * 2 > NSLAB * BM * 4 ? 2 * STAGE * 2 : NSLAB * BM * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM];
@@ -45,22 +47,20 @@ __global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restri
     }
     const long long m0 = (long long)tile * BM;
 
-    int a_row[A_ITEMS], a_pc[A_ITEMS], a_y[A_ITEMS], a_x[A_ITEMS];
-    const bf16 *a_base[A_ITEMS];
-    bool a_ok[A_ITEMS];
+    // piece i of this thread: row = tid / 16 + ROWSTEP * i, 16-B column a_pc = tid % 16 (the same for every piece)
+    const int a_row0 = tid / (BKB / 8), a_pc = tid % (BKB / 8);
+    int a_yx[A_ITEMS];                                     // y << 16 | x, or -1 for rows beyond n_rows
+    unsigned a_off[A_ITEMS];                               // element offset of (frame, cell 0, a_pc * 8)
 #pragma unroll
     for (int i = 0; i < A_ITEMS; i++) {
-        const int it = tid + 512 * i;
-        a_row[i] = it / (BKB / 8);
-        a_pc[i] = it % (BKB / 8);
-        const long long m = m0 + a_row[i];
-        a_ok[i] = m < n_rows;
-        const long long mm = a_ok[i] ? m : 0;
+        const long long m = m0 + a_row0 + ROWSTEP * i;
+        const bool ok = m < n_rows;
+        const long long mm = ok ? m : m0;                  // rows beyond n_rows: any readable address of the tile's frame
         const int f = (int)(mm / cells), cell = (int)(mm % cells);
-        a_y[i] = cell / G;
-        a_x[i] = cell % G;
-        a_base[i] = feat + (long long)f * cells * SSLAM_C + a_pc[i] * 8;
+        a_yx[i] = ok ? ((cell / G) << 16 | (cell % G)) : -1;
+        a_off[i] = (unsigned)((long long)f * cells * SSLAM_C + a_pc * 8 - (long long)(m0 / cells) * cells * SSLAM_C);
     }
+    const bf16 *fbase = feat + (long long)(m0 / cells) * cells * SSLAM_C;   // frame of the tile's first row (uniform)
     u32x4 ra[A_ITEMS];
 #define LOAD_STAGE(S)                                                                                        \
     {                                                                                                        \
@@ -68,27 +68,27 @@ __global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restri
         const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                      \
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;                                                        \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                \
-            const int yy = a_y[i] + dy, xx = a_x[i] + dx;                                                    \
-            const bool ok = a_ok[i] && yy >= 0 && yy < G && xx >= 0 && xx < G;                               \
+            const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;                               \
+            const bool ok = a_yx[i] >= 0 && yy >= 0 && yy < G && xx >= 0 && xx < G;                          \
             const u32x4 v = *reinterpret_cast<const u32x4 *>(                                                \
-                a_base[i] + (ok ? ((long long)yy * G + xx) * SSLAM_C + chunk * BKB : 0));                    \
+                fbase + a_off[i] + (ok ? (unsigned)((yy * G + xx) * SSLAM_C + chunk * BKB) : 0u));           \
             ra[i] = v & (ok ? 0xffffffffu : 0u);                                                             \
         }                                                                                                    \
     }
 #define STORE_STAGE(BUF)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++)                                                      \
-        *reinterpret_cast<u32x4 *>(smem + (BUF) * STAGE + a_row[i] * LDB + a_pc[i] * 8) = ra[i];
+        *reinterpret_cast<u32x4 *>(smem + (BUF) * STAGE + (a_row0 + ROWSTEP * i) * LDB + a_pc * 8) = ra[i];
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) {
         const float bv = b1[wn * 64 + ni * 32 + r];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
     }
-    // B fragment (global k-step G = stage*8 + ks, N tile t): 16 B per lane at ((G * (HS/32) + t) * 64 + lane)
+    // B fragment (global k-step = stage*8 + ks, N tile t): 16 B per lane at ((kstep * (HS/32) + t) * 64 + lane)
     const bf16x8 *bsrc = reinterpret_cast<const bf16x8 *>(w1p) + (wn * 2) * 64 + lane;
     constexpr int GSTR = (HS / 32) * 64;           // bf16x8 elements per global k-step
     bf16x8 bq[RING][2];
@@ -102,21 +102,23 @@ __global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restri
     __syncthreads();
     for (int s = 0; s < NSTB; s++) {
         if (s + 1 < NSTB) LOAD_STAGE(s + 1);
-        const bf16 *As = smem + (s & 1) * STAGE + (wm * 64 + r) * LDB + 8 * h;
+        const bf16 *As = smem + (s & 1) * STAGE + (wm * 32 * MI + r) * LDB + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KSB; ks++) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(As + ks * 16);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(As + 32 * LDB + ks * 16);
+            bf16x8 a[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) a[mi] = *reinterpret_cast<const bf16x8 *>(As + mi * 32 * LDB + ks * 16);
             const bf16x8 b0 = bq[ks % RING][0], b1v = bq[ks % RING][1];
             const long long gn = (long long)s * KSB + ks + RING;
             if (gn < (long long)NSTB * KSB) {
                 bq[ks % RING][0] = bsrc[gn * GSTR];
                 bq[ks % RING][1] = bsrc[gn * GSTR + 64];
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1v, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1v, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b0, acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b1v, acc[mi][1], 0, 0, 0);
+            }
         }
         if (s + 1 < NSTB) STORE_STAGE((s + 1) & 1);
         __syncthreads();
@@ -128,17 +130,17 @@ __global__ __launch_bounds__(512) void selector_bf16_kernel(const bf16 *__restri
     {
         const float w2a = w2[wn * 64 + r], w2b = w2[wn * 64 + 32 + r];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const float h0 = acc[mi][0][e] > 0.0f ? acc[mi][0][e] : 0.0f;
                 const float h1 = acc[mi][1][e] > 0.0f ? acc[mi][1][e] : 0.0f;
                 const float t = bfly32(h0 * w2a + h1 * w2b);
-                if (r == 0) red[wn * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+                if (r == 0) red[wn * BM + wm * 32 * MI + mi * 32 + crow(e, h)] = t;
             }
     }
     __syncthreads();
-    for (int t = tid; t < BM; t += 512) {
+    for (int t = tid; t < BM; t += NTH) {
         const long long m = m0 + t;
         if (m < n_rows) {
             float logit = b2[0];
@@ -203,12 +205,23 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
     if (rows > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (hs == 256) {
-        const int n_tiles = (int)((rows + 127) / 128);
-        hipLaunchKernelGGL((selector_bf16_kernel<2, 4>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
-                           (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+        static const int variant = [] { const char *e = getenv("SSLAM_CONVBF_VARIANT"); return e ? atoi(e) : 2; }();   // measured: 0: 1.08 ms, 1: 1.28 ms, 2: 0.96 ms / 613 frames
+        if (variant == 1) {
+            const int n_tiles = (int)((rows + 127) / 128);
+            hipLaunchKernelGGL((selector_bf16_kernel<1, 4, 4>), dim3(n_tiles), dim3(256), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+                               (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+        } else if (variant == 2) {
+            const int n_tiles = (int)((rows + 255) / 256);
+            hipLaunchKernelGGL((selector_bf16_kernel<2, 4, 4>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+                               (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+        } else {
+            const int n_tiles = (int)((rows + 127) / 128);
+            hipLaunchKernelGGL((selector_bf16_kernel<2, 4, 2>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+                               (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
+        }
     } else if (hs == 128) {
         const int n_tiles = (int)((rows + 255) / 256);
-        hipLaunchKernelGGL((selector_bf16_kernel<4, 2>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
+        hipLaunchKernelGGL((selector_bf16_kernel<4, 2, 2>), dim3(n_tiles), dim3(512), 0, st, (const bf16 *)feat_bf16, (int)rows, G,
                            (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles);
     } else {
         return SSLAM_E_UNSUPPORTED;
