@@ -139,7 +139,13 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float *H = smem, *scratch = smem + H_FLOATS;
     const int tid = threadIdx.x;
-    const long long R0 = (long long)blockIdx.x * RM;
+    // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD one contiguous range of row tiles so that the ~8
+    // tiles gathering from one frame's feature map share that XCD's L2 instead of fetching the frame into all eight
+    long long R0;
+    {
+        const int n_tiles = gridDim.x, b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        R0 = (long long)((x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8) * RM;
+    }
     const float *pk = args.packed;
     const sslam_refiner_layout_t &L = args.lay;
 

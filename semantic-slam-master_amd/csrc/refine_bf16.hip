@@ -116,7 +116,13 @@ __global__ __launch_bounds__(NTHR, 2) void refine_bf16_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) bf16 tile[RM * LDT];
     __shared__ __attribute__((aligned(16))) float part_s[4 * RM], part_q[4 * RM], st_mean[RM], st_rstd[RM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r = lane & 31, h = lane >> 5;
-    const long long R0 = (long long)blockIdx.x * RM;
+    // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD one contiguous range of row tiles so that the ~8
+    // tiles gathering from one frame's feature map share that XCD's L2 instead of fetching the frame into all eight
+    long long R0;
+    {
+        const int n_tiles = gridDim.x, b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        R0 = (long long)((x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8) * RM;
+    }
 
     // ---- phase 0: activation tile <- bf16(gathered features | x_in rows) ---------------------------------------
     {
