@@ -1,0 +1,35 @@
+#!/bin/bash
+# Regenerates the profile artefacts of a round on the GPU box (run from the repo root):  bash tools/profile_round.sh r01
+# Writes gpurun_out/<tag>_*: copy the ones to be judged into profiles/ afterwards.  Raw traces stay in /tmp on the box.
+# rocprofv3 is always given the program itself after `--`; --pmc passes carry only --kernel-trace (no other trace domain).
+set -e
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+RX='selector_saliency|gather_refine|sim_argmax|bn_tokens|preprocess|select_keypoints|intensity_kernel|match_finalize|refine_bf16|selector_bf16|keys_decode'
+BENCH="$ROOT/bench.py --steps 5 --warmup 2"
+
+echo "[1/5] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "[2/5] kernel stats of the same command"
+rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats -d /tmp/ks -o x --output-format csv -- python $BENCH --no-cpu-baseline --no-vit > /dev/null 2>&1
+cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+echo "[3/5] HBM traffic + stall counters (separate --pmc passes)"
+rm -rf /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4
+P="--kernel-trace --kernel-include-regex $RX --output-format csv -o x"
+rocprofv3 --pmc FETCH_SIZE $P -d /tmp/pm1 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE $P -d /tmp/pm2 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA $P -d /tmp/pm3 \
+  -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES $P -d /tmp/pm4 \
+  -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4 > /dev/null
+echo "[4/5] ViT alone"
+python $ROOT/tools/bench_vit.py 448 64 > $OUT/${TAG}_vit_bench.txt
+rm -rf /tmp/kv && rocprofv3 --kernel-trace --stats -d /tmp/kv -o x --output-format csv -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
+cp $(find /tmp/kv -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_vit_kernel_stats.csv
+echo "[5/5] library yardstick + bandwidth probe (context for the roofline fractions, not product code)"
+python $ROOT/tools/yardstick_vit.py > $OUT/${TAG}_yardstick.txt
+python $ROOT/tools/bw_probe.py >> $OUT/${TAG}_yardstick.txt
+echo done
