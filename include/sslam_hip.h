@@ -155,7 +155,8 @@ int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, 
  * (strides in floats; stride 0 broadcasts).  nn12/s12 (n_pairs, n1): first arg-max / max over d2 for each row of
  * d1; nn21/s21 (n_pairs, n2): the column direction.  second12 (n_pairs, n1): the largest similarity of the row with
  * the winner removed (-inf if n2 == 1) - what the ratio tests of visualize_matches.py:116-121 and
- * test/test_descriptor_quality.py:129-131 need, without sorting rows.  s12 / s21 / second12 may be NULL.  * Batched calls (n_pairs >= 16) evaluate the similarity matrix once and reduce the column direction with 64-bit
+ * test/test_descriptor_quality.py:129-131 need, without sorting rows.  s12 / s21 / second12 may be NULL.
+ * Batched calls (n_pairs >= 16) evaluate the similarity matrix once and reduce the column direction with 64-bit
  * (value, ~index) keys and atomic max - deterministic - using n_pairs*n2*8 bytes of stream-ordered scratch
  * (hipMallocAsync / hipFreeAsync on `stream`); smaller calls evaluate it once per direction and allocate nothing.
  * Environment SSLAM_M1_VARIANT = 1 / 2 forces the scratch-free / the single-evaluation form. */
