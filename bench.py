@@ -100,10 +100,25 @@ def cpu_baseline(imgs, toks, ssd, rsd, size, K, budget_s=12.0):
     reps = int(max(1, min(40, round(budget_s / max(t1, 1e-3)))))
     ts = [t1] + [run(nmax) for _ in range(reps - 1)]
     t = float(np.mean(ts))
-    return dict(value=round(nmax / t, 2), unit="frames/s", cores=nthr, kind="port",
+    # the same port on ONE thread (SURVEY 8d asks for both), on a shorter sample of the same frames
+    ora.set_num_threads(1)
+    n1 = min(nmax, 16)
+    run(2)
+    t_1 = run(n1)
+    ora.set_num_threads(nthr)
+    return dict(value=round(nmax / t, 2), unit="frames/s", cores=nthr, kind="port", value_1core=round(n1 / t_1, 2),
+                median=round(nmax / float(np.median(ts)), 2),
                 sample=f"{nmax} frames of the same workload (each extracted once + {nmax - 1} consecutive-pair matches), "
                        f"repeated {len(ts)}x = {sum(ts):.1f} s of CPU work; oracle/sslam_oracle.c (AVX2+FMA, OpenMP) on "
                        f"{nthr} threads; mean of repeats")
+
+
+def path_roofline(fps, grid, K, hidden, h, w):
+    cells = grid * grid
+    flop = cells * hidden * 3456 * 2 + cells * hidden * 2 + K * 1572864 + K * 384 * 8 + K * K * 128 * 2
+    bytes_io = h * w * 3 + (5 + cells) * 384 * 4 + K * (8 + 4 + 4 + 512) + K * 20
+    return {"flop_per_frame": flop, "mfma_tflops": round(fps * flop / 1e12, 2), "frac_of_fp32_matrix_peak": round(fps * flop / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+            "compulsory_bytes_per_frame": bytes_io, "hbm_tb_s": round(fps * bytes_io / 1e12, 3), "frac_of_hbm_8tb_s": round(fps * bytes_io / 8e12, 4)}
 
 
 def main():
@@ -287,6 +302,8 @@ def main():
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes": n * cells * 384 * 4 + n * cells * 4 + 9 * 384 * pipe.selector.hidden * 4,
                          "flop_per_launch": conv_flop, "launch_ms": stage_ms["A3_selector_saliency"]},
+            # SURVEY 8d path-level figures: authored-path FLOP (A3 + A7 + A6 + one M1 per frame) and compulsory bytes per frame
+            "path_roofline": path_roofline(n * world * args.steps / dt, grid, K, pipe.selector.hidden, h, w),
             "stage_ms": stage_ms,
             "parity": {"frames_checked_vs_oracle": nchk, "bit_exact": ok},
             "matches_per_pair": round(float(out["match_count"].float().mean().item()), 1),
