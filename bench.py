@@ -283,7 +283,7 @@ def main():
                 traffic = None
         # parity spot-check against the oracle on the first frames (outside the timed region)
         from oracle import ora
-        nchk = 3
+        nchk = min(3, n)
         o_feat = ora.bn_tokens(toks[:nchk].cpu().numpy())[0].reshape(nchk, grid, grid, 384)
         o_kp, o_sc, o_idx, _ = ora.select_keypoints(ora.selector_saliency(o_feat, ssd), K)
         o_desc = ora.refine(ora.gather(o_feat, o_kp), rsd)

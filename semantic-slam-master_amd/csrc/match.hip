@@ -285,7 +285,10 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
         unsigned long long *keys = nullptr;
         const size_t bytes = (size_t)n_pairs * n2 * sizeof(unsigned long long);
         if (hipMallocAsync((void **)&keys, bytes, st) != hipSuccess) return SSLAM_E_LAUNCH;   // stream-ordered scratch
-        if (hipMemsetAsync(keys, 0, bytes, st) != hipSuccess) return SSLAM_E_LAUNCH;
+        if (hipMemsetAsync(keys, 0, bytes, st) != hipSuccess) {
+            (void)hipFreeAsync(keys, st);
+            return SSLAM_E_LAUNCH;
+        }
         hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
                            desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys);
         SSLAM_CHECK_LAUNCH();
