@@ -128,3 +128,56 @@ def unit_descriptors(seed: int, n: int, d: int = 128, dup: int = 0) -> np.ndarra
         src = rng.integers(0, n - dup, size=dup)
         x[n - dup:] = x[src]
     return x
+
+
+def descriptor_pair(seed: int, n: int, m: int, dup: int, noise: float = 0.25):
+    """Two descriptor sets with known correspondences and duplicated rows (== tests/golden/make_golden.py:pair)."""
+    d1 = unit_descriptors(seed, n, 128, dup)
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    perm = (rng.permutation(max(n, m)) % n)[:m]
+    d2 = d1[perm] + noise * rng.standard_normal((m, 128)).astype(np.float32) / np.sqrt(128).astype(np.float32)
+    d2 = (d2 / np.linalg.norm(d2.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    if dup:
+        d2[m - dup // 2:] = d2[: dup // 2]
+    s1 = (0.2 + 0.8 * rng.random(n)).astype(np.float32)
+    s2 = (0.2 + 0.8 * rng.random(m)).astype(np.float32)
+    i1 = rng.random(n).astype(np.float32)
+    i2 = rng.random(m).astype(np.float32)
+    return d1, d2, s1, s2, i1, i2
+
+
+def wide_map(seed: int):
+    """Case `seed` of the wide selection fixture (tests/golden/select_wide.npz): a tie-free saliency map (uniform /
+    a band hugging 0.5 / smooth bumps) with a random grid, K, NMS radius and percentile -> (map, K, radius, pct)."""
+    rng = np.random.Generator(np.random.PCG64(60_000 + seed))
+    g = int(rng.integers(6, 61))
+    kind = seed % 3
+    while True:
+        u = rng.random((g, g))
+        if kind == 0:
+            m = u
+        elif kind == 1:
+            m = 0.5 + 0.02 * (u - 0.5)
+        else:
+            yy, xx = np.mgrid[0:g, 0:g] / g
+            m = 0.5 + 0.4 * np.sin(6.0 * xx + seed) * np.cos(5.0 * yy - seed) + 0.05 * u
+        m = m.astype(np.float32)
+        if np.unique(m).size == m.size:
+            break
+    K = int(rng.integers(1, g * g + 1))
+    radius = int(rng.integers(0, 4))
+    pct = float(rng.choice([0.1, 0.25, 0.5, 0.6, 0.8]))
+    return m, K, radius, pct
+
+
+def wide_pair(seed: int):
+    """Case `seed` of the wide matcher fixture (tests/golden/match_wide.npz)."""
+    rng = np.random.Generator(np.random.PCG64(70_000 + seed))
+    n, m = int(rng.integers(2, 600)), int(rng.integers(2, 600))
+    dup = int(rng.integers(0, n // 4 + 1))
+    d1, d2, s1, s2, i1, i2 = descriptor_pair(5000 + seed, n, m, min(dup, m // 2 * 2), noise=float(rng.choice([0.1, 0.25, 0.5])))
+    kw = dict(saliency_weight=float(np.round(rng.random(), 3)), min_saliency=float(np.round(rng.random() * 0.6, 3)),
+              min_descriptor_sim=float(np.round(0.3 + 0.6 * rng.random(), 3)), min_intensity=float(np.round(rng.random() * 0.4, 3)))
+    if seed % 2:
+        kw = dict(kw, intensity1=i1, intensity2=i2)
+    return d1, d2, s1, s2, kw

@@ -284,6 +284,28 @@ def test_sim_argmax_both_forms(T, hip, variant, n, m, dup, monkeypatch):
         assert_bits(sec.cpu().numpy()[p], S.max(1), "second12")
 
 
+def test_wide_reference_goldens_on_gpu(T, hip):
+    """The wide randomised fixtures (reference outputs, tests/golden/make_golden_wide.py) straight against the HIP kernels:
+    64 selection cases and 32 matcher cases - indices / match pairs equal the reference's."""
+    g = gold("select_wide")
+    for s in range(int(g["count"])):
+        m, K, radius, pct = synth.wide_map(s)
+        kp, sc, idx, px, st = _select(T, hip, m[None], K, radius, pct)
+        want = g[f"s{s}_idx"]
+        if want.size == 0:
+            assert st[0] == 1, s                       # the reference raises here (SURVEY H6)
+            continue
+        assert st[0] == 0 and np.array_equal(idx[0], want.astype(np.int32)), (s, m.shape, K, radius, pct)
+        assert_bits(sc[0], g[f"s{s}_scores"], f"scores {s}")
+    g = gold("match_wide")
+    for s in range(int(g["count"])):
+        d1, d2, s1, s2, kw = synth.wide_pair(s)
+        mt, q = _match(T, hip, d1, d2, s1, s2, kw["saliency_weight"], kw["min_saliency"], kw["min_descriptor_sim"],
+                       kw.get("intensity1"), kw.get("intensity2"), kw["min_intensity"])
+        assert np.array_equal(mt, g[f"p{s}_matches"].astype(np.int64).reshape(-1, 2)), s
+        assert np.abs(q - g[f"p{s}_quality"]).max(initial=0.0) < 1e-6, s
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 def test_end_to_end_golden(T, hip):
     """tokens + images -> keypoints, descriptors, intensity, matches: indices / pairs equal the reference's."""

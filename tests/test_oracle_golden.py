@@ -320,3 +320,39 @@ def test_batched_mnn_padding_m3():
         got = np.stack([idx1, nn12[idx1]], axis=1)
         assert np.array_equal(got, want[b, :len(got)])
         assert not want[b, len(got):].any()
+
+
+# ------------------------------------------------------------------------------ wide, randomised reference-pinned sets
+def test_select_wide_vs_reference():
+    """64 random (grid, K, radius, percentile, map kind) cases: the oracle's keypoint indices and scores equal what the
+    reference's KeypointSelector.select_keypoints returned (tests/golden/make_golden_wide.py); where the reference
+    raises (K beyond what the grid can supply) the oracle flags the frame."""
+    g = gold("select_wide")
+    raised = 0
+    for s in range(int(g["count"])):
+        m, K, radius, pct = synth.wide_map(s)
+        kp, sc, idx, st = ora.select_keypoints(m, K, radius, pct)
+        want = g[f"s{s}_idx"]
+        if want.size == 0:
+            assert st[0] == 1, s
+            raised += 1
+            continue
+        assert st[0] == 0, s
+        assert np.array_equal(idx[0], want.astype(np.int32)), (s, m.shape, K, radius, pct)
+        assert np.array_equal(sc[0].view(np.uint32), g[f"s{s}_scores"].view(np.uint32)), s
+    assert raised < int(g["count"]) // 2
+
+
+def test_match_wide_vs_reference():
+    """32 random descriptor pairs (ragged sizes, duplicated rows = exact ties, random thresholds, with and without the
+    intensity test): match pairs equal the reference's SequenceMatcher.match_with_quality, quality within 1e-6."""
+    g = gold("match_wide")
+    total = 0
+    for s in range(int(g["count"])):
+        d1, d2, s1, s2, kw = synth.wide_pair(s)
+        mt, q = ora.match_with_quality(d1, d2, s1, s2, **kw)
+        want = g[f"p{s}_matches"].astype(np.int64).reshape(-1, 2)
+        assert np.array_equal(mt, want), (s, d1.shape, d2.shape, kw.keys())
+        assert np.abs(q - g[f"p{s}_quality"]).max(initial=0.0) < 1e-6, s
+        total += len(mt)
+    assert total > 500
