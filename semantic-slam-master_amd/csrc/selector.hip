@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
         if (s + 1 < NSTAGE) LOAD_STAGE(s + 1);
         const float *As = smem + (s & 1) * STAGE_FLOATS + (wm * 64 + r) * LDT + 4 * h;
         const float *Bs = smem + (s & 1) * STAGE_FLOATS + BM * LDT + (wn * 32 * NI + r) * LDT + 4 * h;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(As + 8 * g);
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
                     acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
                 }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (s + 1 < NSTAGE) STORE_STAGE((s + 1) & 1);
         __syncthreads();
     }
