@@ -113,6 +113,23 @@ def cpu_baseline(imgs, toks, ssd, rsd, size, K, budget_s=12.0):
                        f"{nthr} threads; mean of repeats")
 
 
+def measured_mfma_peak():
+    """The matrix pipe's own rate on THIS box (tools/microbench/mfma_peak.hip: every wave issues independent
+    v_mfma_f32_32x32x2_f32 chains, no memory traffic), as ~6 ms bursts - the duty cycle of the conv inside the pass.
+    It sits below the nominal 157.3 TFLOP/s (2.4 GHz): under matrix load the clock is about 2.27 GHz."""
+    import ctypes
+    so = os.path.join(ROOT, "tools", "microbench", "libmfma_peak.so")
+    if not os.path.exists(so):
+        return None
+    L = ctypes.CDLL(so)
+    L.mfma_peak_tflops.restype = ctypes.c_double
+    L.mfma_peak_tflops.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mfma_peak_tflops(0, 200)                                   # module load
+    burst = [L.mfma_peak_tflops(0, 3080) for _ in range(3)]
+    return {"f32_burst_tflops": round(float(np.median(burst)), 1),
+            "source": "tools/microbench/mfma_peak.hip (pure MFMA loop, 2 waves/SIMD x 4 independent accumulators, ~6 ms)"}
+
+
 def path_roofline(fps, grid, K, hidden, h, w):
     cells = grid * grid
     flop = cells * hidden * 3456 * 2 + cells * hidden * 2 + K * 1572864 + K * 384 * 8 + K * K * 128 * 2
@@ -289,6 +306,7 @@ def main():
         o_desc = ora.refine(ora.gather(o_feat, o_kp), rsd)
         ok = bool(np.array_equal(out["idx"][:nchk].cpu().numpy(), o_idx) and
                   np.array_equal(out["descriptors"][:nchk].cpu().numpy().view(np.uint32), o_desc.view(np.uint32)))
+        mpeak = measured_mfma_peak() if world == 1 else None
         res = {
             "metric": METRIC, "value": round(n * world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -301,7 +319,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes": n * cells * 384 * 4 + n * cells * 4 + 9 * 384 * pipe.selector.hidden * 4,
-                         "flop_per_launch": conv_flop, "launch_ms": stage_ms["A3_selector_saliency"]},
+                         "flop_per_launch": conv_flop, "launch_ms": stage_ms["A3_selector_saliency"],
+                         # context: what the matrix pipe itself sustains on this box (power / clock limited), and the kernel against it
+                         "peak_measured": mpeak,
+                         "frac_of_measured_peak": (round(achieved / mpeak["f32_burst_tflops"], 4) if mpeak else None)},
             # SURVEY 8d path-level figures: authored-path FLOP (A3 + A7 + A6 + one M1 per frame) and compulsory bytes per frame
             "path_roofline": path_roofline(n * world * args.steps / dt, grid, K, pipe.selector.hidden, h, w),
             "stage_ms": stage_ms,
