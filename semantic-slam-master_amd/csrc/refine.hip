@@ -68,12 +68,22 @@ __device__ __forceinline__ void gemm_lds(const float *H, const float *__restrict
     f32x4 an = *reinterpret_cast<const f32x4 *>(A);
 #pragma unroll 1
     for (int g = 0; g < NKG; g += 3) {
+        // the refills are UNCONDITIONAL (clamped index, a redundant reload in the last trip): with a branch around them the
+        // compiler cannot count the loads in flight and falls back to s_waitcnt vmcnt(0) before the third step of every
+        // trip, which drains the whole prefetch ring
+        // (sched_barrier: program order = issue order, or the scheduler sinks the loads next to their uses)
         LOAD_B(b2, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
         STEP(b0, g);
-        if (g + 3 < NKG) LOAD_B(b0, g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD_B(b0, min(g + 3, NKG - 1));
+        __builtin_amdgcn_sched_barrier(0);
         STEP(b1, g + 1);
-        if (g + 4 < NKG) LOAD_B(b1, g + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD_B(b1, min(g + 4, NKG - 1));
+        __builtin_amdgcn_sched_barrier(0);
         STEP(b2, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #undef LOAD_B
 #undef STEP
