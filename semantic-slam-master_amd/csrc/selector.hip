@@ -28,7 +28,7 @@ constexpr int NCHUNK = SSLAM_C / BK;
 constexpr int NSTAGE = 9 * NCHUNK;
 
 template <int WM, int WN, int NI, bool BDIRECT>
-__global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__restrict__ feat, int n_rows, int G,
+__global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_saliency_kernel(const float *__restrict__ feat, int n_rows, int G,
                                                                  const float *__restrict__ w1p,
                                                                  const float *__restrict__ b1,
                                                                  const float *__restrict__ w2,
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
     }
 
     float4 ra_lo[A_ITEMS], ra_hi[A_ITEMS], rb[B_ITEMS];
+    bool ra_ok[A_ITEMS];
 
 #define LOAD_STAGE(S)                                                                                              \
     {                                                                                                              \
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
             const bool ok = a_ok[i] && yy >= 0 && yy < G && xx >= 0 && xx < G;                                     \
             const float4 *p = reinterpret_cast<const float4 *>(                                                    \
                 a_base[i] + (ok ? ((long long)yy * G + xx) * SSLAM_C + chunk * BK : 0));                           \
-            float4 v0 = p[0], v1 = p[1];                                                                           \
-            ra_lo[i] = make_float4(ok ? v0.x : 0.f, ok ? v0.y : 0.f, ok ? v0.z : 0.f, ok ? v0.w : 0.f);            \
-            ra_hi[i] = make_float4(ok ? v1.x : 0.f, ok ? v1.y : 0.f, ok ? v1.z : 0.f, ok ? v1.w : 0.f);            \
+            ra_lo[i] = p[0];          /* raw: the zero padding is applied at STORE_STAGE, so that nothing waits */  \
+            ra_hi[i] = p[1];          /* for these loads before the stage's MFMAs have been issued             */  \
+            ra_ok[i] = ok;                                                                                         \
         }                                                                                                          \
         if (!BDIRECT) {                                                                                            \
             const float4 *wp = reinterpret_cast<const float4 *>(w1p + (long long)s_ * HS * BK);                    \
@@ -104,7 +105,10 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
         float *Bs_ = As_ + BM * LDT;                                                                               \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                      \
             float4 ev, od;                                                                                         \
-            kp8_split(ra_lo[i], ra_hi[i], ev, od);                                                                 \
+            const bool k_ = ra_ok[i];                                                                              \
+            const float4 lo_ = make_float4(k_ ? ra_lo[i].x : 0.f, k_ ? ra_lo[i].y : 0.f, k_ ? ra_lo[i].z : 0.f, k_ ? ra_lo[i].w : 0.f); \
+            const float4 hi_ = make_float4(k_ ? ra_hi[i].x : 0.f, k_ ? ra_hi[i].y : 0.f, k_ ? ra_hi[i].z : 0.f, k_ ? ra_hi[i].w : 0.f); \
+            kp8_split(lo_, hi_, ev, od);                                                                           \
             float *d = As_ + a_row[i] * LDT + a_kq[i] * 8;                                                         \
             *reinterpret_cast<float4 *>(d) = ev;                                                                   \
             *reinterpret_cast<float4 *>(d + 4) = od;                                                               \
@@ -157,10 +161,6 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
                 b[ni] = BDIRECT ? bq[g][ni] : *reinterpret_cast<const f32x4 *>(Bs + ni * 32 * LDT + 8 * g);
-            if (BDIRECT && s + 1 < NSTAGE) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)((s + 1) * (BK / 8) + g) * HS + ni * 32) * 2];
-            }
 #pragma unroll
             for (int st = 0; st < 4; st++)
 #pragma unroll
@@ -168,6 +168,12 @@ __global__ __launch_bounds__(512) void selector_saliency_kernel(const float *__r
                     acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
                     acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
                 }
+            // slot g is refilled with k-group g of the NEXT stage once its MFMAs have been issued (in place: no second
+            // set of registers), i.e. three quarters of a stage before it is needed
+            if (BDIRECT && s + 1 < NSTAGE) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)((s + 1) * (BK / 8) + g) * HS + ni * 32) * 2];
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         if (s + 1 < NSTAGE) STORE_STAGE((s + 1) & 1);
