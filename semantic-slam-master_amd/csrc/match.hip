@@ -28,15 +28,15 @@ template <int ROWS>
 struct Stager {
     static constexpr int ITEMS = ROWS * 16 / 512;
     float4 lo[ITEMS], hi[ITEMS];
+    bool ok[ITEMS];         // rows beyond n_valid are zeroed at store time: nothing waits for the loads before the MFMAs
     __device__ __forceinline__ void load(const float *__restrict__ src, int first, int n_valid, int tid) {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const int it = tid + 512 * i, row = it >> 4, g = it & 15;
-            const bool ok = first + row < n_valid;
-            const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(ok ? first + row : 0) * SSLAM_D + 8 * g);
-            const float4 a = p[0], b = p[1];
-            lo[i] = make_float4(ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f);
-            hi[i] = make_float4(ok ? b.x : 0.f, ok ? b.y : 0.f, ok ? b.z : 0.f, ok ? b.w : 0.f);
+            ok[i] = first + row < n_valid;
+            const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(ok[i] ? first + row : 0) * SSLAM_D + 8 * g);
+            lo[i] = p[0];
+            hi[i] = p[1];
         }
     }
     __device__ __forceinline__ void store(float *dst, int tid) const {
@@ -44,7 +44,9 @@ struct Stager {
         for (int i = 0; i < ITEMS; i++) {
             const int it = tid + 512 * i, row = it >> 4, g = it & 15;
             float4 ev, od;
-            kp8_split(lo[i], hi[i], ev, od);
+            const bool k = ok[i];
+            kp8_split(make_float4(k ? lo[i].x : 0.f, k ? lo[i].y : 0.f, k ? lo[i].z : 0.f, k ? lo[i].w : 0.f),
+                      make_float4(k ? hi[i].x : 0.f, k ? hi[i].y : 0.f, k ? hi[i].z : 0.f, k ? hi[i].w : 0.f), ev, od);
             *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g) = ev;
             *reinterpret_cast<float4 *>(dst + row * LDD + 8 * g + 4) = od;
         }
