@@ -168,12 +168,15 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
                     acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
                     acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
                 }
-            // slot g is refilled with k-group g of the NEXT stage once its MFMAs have been issued (in place: no second
-            // set of registers), i.e. three quarters of a stage before it is needed
-            if (BDIRECT && s + 1 < NSTAGE) {
+            // slots are refilled in place with the k-groups of the NEXT stage once their MFMAs have been issued: the first
+            // half of the ring in the middle of the stage (pinned there), the second half at its end
+            if (BDIRECT && s + 1 < NSTAGE && (g == BK / 16 - 1 || g == BK / 8 - 1)) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)((s + 1) * (BK / 8) + g) * HS + ni * 32) * 2];
+                for (int gg = g + 1 - BK / 16; gg <= g; gg++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) bq[gg][ni] = bsrc[((long long)((s + 1) * (BK / 8) + gg) * HS + ni * 32) * 2];
             }
+            if (BDIRECT && g == BK / 16 - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
         if (s + 1 < NSTAGE) STORE_STAGE((s + 1) & 1);
