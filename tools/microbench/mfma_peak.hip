@@ -115,5 +115,23 @@ int main() {
             const double flop = (double)256 * k * 4 * iters * 8 * nacc * 2.0 * 32 * 32 * 2;
             printf("f32 sweep: %d waves/SIMD x %d accumulators  %8.3f ms  %8.1f TFLOP/s\n", k, nacc, ms, flop / ms / 1e9);
         }
+    // the occupancies the library's fp32 kernels actually run at: 3 waves/SIMD x 3 accumulators (descriptor MLP),
+    // 4 x 4 (saliency CNN, two workgroups per CU), 2 x 1 (matcher)
+    for (int cfg = 0; cfg < 4; cfg++) {
+        const int k = cfg == 0 ? 3 : (cfg == 1 ? 3 : (cfg == 2 ? 6 : 2)), nacc = cfg == 0 ? 3 : (cfg == 1 ? 6 : (cfg == 2 ? 3 : 1));
+        hipDeviceSynchronize();
+        usleep(20000);
+        const int iters = 1540 * 16 / k / nacc;
+        hipEventRecord(e0);
+        if (nacc == 1) hipLaunchKernelGGL(f32_kernel<1>, dim3(256 * k), dim3(256), 0, 0, out, iters, 1.0f, 1e-30f);
+        if (nacc == 3) hipLaunchKernelGGL(f32_kernel<3>, dim3(256 * k), dim3(256), 0, 0, out, iters, 1.0f, 1e-30f);
+        if (nacc == 6) hipLaunchKernelGGL(f32_kernel<6>, dim3(256 * k), dim3(256), 0, 0, out, iters, 1.0f, 1e-30f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)256 * k * 4 * iters * 8 * nacc * 2.0 * 32 * 32 * 2;
+        printf("f32 sweep: %d waves/SIMD x %d accumulators  %8.3f ms  %8.1f TFLOP/s\n", k, nacc, ms, flop / ms / 1e9);
+    }
     return 0;
 }
