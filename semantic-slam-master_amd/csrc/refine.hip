@@ -115,27 +115,52 @@ __device__ __forceinline__ void layernorm_rows(float *H, const float *__restrict
         gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
         bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
     }
-#pragma unroll 2
-    for (int rr = 0; rr < 8; rr++) {
-        float *p = H + (wave * 8 + rr) * LDH + 8 * j;
-        const float4 ev = *reinterpret_cast<const float4 *>(p), od = *reinterpret_cast<const float4 *>(p + 4);
-        float x[8] = {ev.x, od.x, ev.y, od.y, ev.z, od.z, ev.w, od.w};
-        float s = x[0];
+    // All 8 rows of the wave go through every butterfly step TOGETHER: the 12 cross-lane steps per row are LDS-path
+    // round trips (ds_bpermute, several hundred cycles each while the other waves stream MFMA operands), and row by row
+    // they added up to 96 serial round trips per call - a quarter of the workgroup's lifetime.  Per row the operations
+    // and their order are unchanged (oracle layernorm384).
+    constexpr int NR = RM / (NTHR / 64);      // rows per wave
+    float x[NR][8], s[NR];
 #pragma unroll
-        for (int i = 1; i < 8; i++) s = s + x[i];
-        const float mean = bfly64(act ? s : 0.0f) / 384.0f;
+    for (int rr = 0; rr < NR; rr++) {
+        const float *p = H + (wave * NR + rr) * LDH + 8 * j;
+        const float4 ev = *reinterpret_cast<const float4 *>(p), od = *reinterpret_cast<const float4 *>(p + 4);
+        x[rr][0] = ev.x; x[rr][1] = od.x; x[rr][2] = ev.y; x[rr][3] = od.y;
+        x[rr][4] = ev.z; x[rr][5] = od.z; x[rr][6] = ev.w; x[rr][7] = od.w;
+        float t = x[rr][0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) t = t + x[rr][i];
+        s[rr] = act ? t : 0.0f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) s[rr] = s[rr] + __shfl_xor(s[rr], m);
+    float mean[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        mean[rr] = s[rr] / 384.0f;
         float s2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float d = x[i] - mean;
+            const float d = x[rr][i] - mean[rr];
             s2 = __builtin_fmaf(d, d, s2);
         }
-        const float var = bfly64(act ? s2 : 0.0f) / 384.0f;
+        s[rr] = act ? s2 : 0.0f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) s[rr] = s[rr] + __shfl_xor(s[rr], m);
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const float var = s[rr] / 384.0f;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         float y[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) y[i] = __builtin_fmaf((x[i] - mean) * rstd, gm[i], bt[i]);
+        for (int i = 0; i < 8; i++) y[i] = __builtin_fmaf((x[rr][i] - mean[rr]) * rstd, gm[i], bt[i]);
         if (act) {
+            float *p = H + (wave * NR + rr) * LDH + 8 * j;
             *reinterpret_cast<float4 *>(p) = make_float4(y[0], y[2], y[4], y[6]);
             *reinterpret_cast<float4 *>(p + 4) = make_float4(y[1], y[3], y[5], y[7]);
         }
