@@ -39,8 +39,10 @@ struct RefArgs {
 
 // acc[t] (32 rows x 32 cols each, t-th N tile of this wave) = bias + H(64 x 384) . W^T, one fma chain per output in
 // increasing k.  B fragments come straight from global memory (fragment-ordered packed weights), ring of 3 k-groups.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int NT>
-__device__ __forceinline__ void gemm_lds(const float *H, const float *__restrict__ wp, const float *__restrict__ bias,
+__device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t wrs, int w_off, const float *__restrict__ bias,
                                          int tid, f32x16 (&acc)[NT]) {
     constexpr int N = 128 * NT;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
@@ -50,12 +52,15 @@ __device__ __forceinline__ void gemm_lds(const float *H, const float *__restrict
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = bv;
     }
-    // lane's B fragment of k-group g, tile t: 16 B at ((g*N + n)*8 + 4h) floats, n = wn*32*NT + t*32 + r
-    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(wp) + ((wn * 32 * NT + r) * 2 + h);
+    // lane's B fragment of k-group g, tile t: 16 B at ((g*N + n)*8 + 4h) floats, n = wn*32*NT + t*32 + r.  Buffer loads:
+    // address = descriptor base + 32-bit lane offset (constant) + SCALAR offset of (layer, k-group, tile), so the k loop
+    // carries no vector address arithmetic at all - every non-MFMA instruction costs matrix-pipe issue time
+    const int loff = ((wn * 32 * NT + r) * 2 + h) * 16;
     const float *A = H + (wm * 32 + r) * LDH + 4 * h;
     f32x4 b0[NT], b1[NT], b2[NT];
 #define LOAD_B(dst, g)                                                               \
-    _Pragma("unroll") for (int t = 0; t < NT; t++) dst[t] = bsrc[((g) * N + t * 32) * 2];
+    _Pragma("unroll") for (int t = 0; t < NT; t++)                                   \
+        dst[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, w_off + ((g) * N + t * 32) * 32, 0));
 #define STEP(cur, g)                                                                  \
     {                                                                                 \
         const f32x4 a = an;                                                           \
@@ -183,6 +188,8 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     }
     const float *pk = args.packed;
     const sslam_refiner_layout_t &L = args.lay;
+    // buffer descriptor over the packed weights (raw buffer, 32-bit element format word as on gfx90a/gfx94x/gfx950)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pk), 0, (int)(L.total * 4), 0x00020000);
 
     // ---- phase 0: fill the activation tile (gathered features, or rows of x_in) --------------------------------
     {
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
 
     // ---- input_proj + ReLU (descriptor_refiner.py:76) -----------------------------------------------------------
     f32x16 X[3], acc[3];
-    gemm_lds<3>(H, pk + L.in_w, pk + L.in_b, tid, acc);
+    gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     for (int b = 0; b < L.n_blocks; b++) {
         layernorm_rows(H, pk + L.blk[b][0], pk + L.blk[b][1], tid);
         __syncthreads();
-        gemm_lds<3>(H, pk + L.blk[b][2], pk + L.blk[b][3], tid, acc);
+        gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
         __syncthreads();
         layernorm_rows(H, pk + L.blk[b][4], pk + L.blk[b][5], tid);
         __syncthreads();
-        gemm_lds<3>(H, pk + L.blk[b][6], pk + L.blk[b][7], tid, acc);
+        gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
 
     // ---- output_proj + L2 normalise (:83-86; F.normalize eps 1e-12) --------------------------------------------
     f32x16 o[1];
-    gemm_lds<1>(H, pk + L.out_w, pk + L.out_b, tid, o);
+    gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);
     {
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
         float *part = scratch;  // [64 rows][4 waves]
