@@ -59,22 +59,30 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     }
     const long long m0 = (long long)tile * BM;
 
-    // per-thread A rows (fixed for the whole K loop)
-    int a_row[A_ITEMS], a_kq[A_ITEMS], a_y[A_ITEMS], a_x[A_ITEMS];
-    const float *a_base[A_ITEMS];
-    bool a_ok[A_ITEMS];
+    // per-thread A rows (fixed for the whole K loop).  Loads are buffer loads: descriptor base + 32-bit lane offset of the
+    // row's own cell + a SCALAR offset for (tap, channel chunk) - no per-stage vector address arithmetic (every non-MFMA
+    // instruction costs matrix-pipe issue time).  A tap outside the grid reads some other cell (or, outside the
+    // buffer, zeros from the descriptor's range check); it is zeroed at STORE_STAGE by the precomputed 9-bit validity mask.
+    const __amdgpu_buffer_rsrc_t frs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 4u)), 0x00020000);
+    int a_row[A_ITEMS], a_kq[A_ITEMS], a_voff[A_ITEMS], a_mask[A_ITEMS];
 #pragma unroll
     for (int i = 0; i < A_ITEMS; i++) {
         const int it = tid + 512 * i;
         a_row[i] = it >> 2;
         a_kq[i] = it & 3;
         const long long m = m0 + a_row[i];
-        a_ok[i] = m < n_rows;
-        const long long mm = a_ok[i] ? m : 0;
-        const int f = (int)(mm / cells), cell = (int)(mm % cells);
-        a_y[i] = cell / G;
-        a_x[i] = cell % G;
-        a_base[i] = feat + (long long)f * cells * SSLAM_C + a_kq[i] * 8;
+        const bool okr = m < n_rows;
+        const long long mm = okr ? m : 0;
+        const int cell = (int)(mm % cells), y = cell / G, x = cell % G;
+        a_voff[i] = (int)((unsigned)mm * (SSLAM_C * 4u) + a_kq[i] * 32u);
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            mk |= (okr && yy >= 0 && yy < G && xx >= 0 && xx < G) ? (1 << t) : 0;
+        }
+        a_mask[i] = mk;
     }
 
     float4 ra_lo[A_ITEMS], ra_hi[A_ITEMS], rb[B_ITEMS];
@@ -84,15 +92,14 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     {                                                                                                              \
         const int s_ = (S);                                                                                        \
         const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                            \
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;                                                              \
+        /* the tap shift can be negative and a buffer's scalar offset is unsigned: it goes into the lane offset (one  */ \
+        /* add; a wrapped / too large result fails the range check and reads zeros), the chunk into the scalar part */ \
+        const int toff_ = ((tap / 3 - 1) * G + (tap % 3 - 1)) * (SSLAM_C * 4), soff_ = chunk * (BK * 4);             \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                      \
-            const int yy = a_y[i] + dy, xx = a_x[i] + dx;                                                          \
-            const bool ok = a_ok[i] && yy >= 0 && yy < G && xx >= 0 && xx < G;                                     \
-            const float4 *p = reinterpret_cast<const float4 *>(                                                    \
-                a_base[i] + (ok ? ((long long)yy * G + xx) * SSLAM_C + chunk * BK : 0));                           \
-            ra_lo[i] = p[0];          /* raw: the zero padding is applied at STORE_STAGE, so that nothing waits */  \
-            ra_hi[i] = p[1];          /* for these loads before the stage's MFMAs have been issued             */  \
-            ra_ok[i] = ok;                                                                                         \
+            const int vt_ = a_voff[i] + toff_;                                                                     \
+            ra_lo[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, vt_, soff_, 0));             \
+            ra_hi[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, vt_, soff_ + 16, 0));        \
+            ra_ok[i] = (a_mask[i] >> tap) & 1;                                                                     \
         }                                                                                                          \
         if (!BDIRECT) {                                                                                            \
             const float4 *wp = reinterpret_cast<const float4 *>(w1p + (long long)s_ * HS * BK);                    \
@@ -134,6 +141,9 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     }
     // direct-B: lane's fragment of (stage s, k-group g, tile ni) = 16 B at (((s*4+g)*HS + n)*8 + 4h) floats
     const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 32 * NI + r) * 2 + h);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w1p), 0, 9 * SSLAM_C * HS * 4, 0x00020000);
+    const int b_voff = ((wn * 32 * NI + r) * 2 + h) * 16;
 
     // B fragments are one continuous stream over (stage, k-group) in the packed weights: slot g of the ring always holds
     // k-group g of the current stage and is refilled with k-group g of the NEXT stage right after its MFMAs, i.e. every
@@ -174,7 +184,9 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 #pragma unroll
                 for (int gg = g + 1 - BK / 16; gg <= g; gg++)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ni++) bq[gg][ni] = bsrc[((long long)((s + 1) * (BK / 8) + gg) * HS + ni * 32) * 2];
+                    for (int ni = 0; ni < NI; ni++)
+                        bq[gg][ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            wrs, b_voff, (((s + 1) * (BK / 8) + gg) * HS + ni * 32) * 32, 0));
             }
             if (BDIRECT && g == BK / 16 - 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -231,7 +243,7 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     if (!feat || !w1_packed || !b1 || !w2 || !b2 || !sal || n_frames <= 0 || G <= 0) return SSLAM_E_INVALID;
     if (((uintptr_t)feat | (uintptr_t)w1_packed) & 15) return SSLAM_E_INVALID;
     const long long rows = (long long)n_frames * G * G;
-    if (rows > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    if (rows * (long long)(SSLAM_C * 4) > 0xffffffffLL) return SSLAM_E_UNSUPPORTED;   // one buffer descriptor spans the feature map
     hipStream_t st = (hipStream_t)stream;
     // tuning knob; measured on MI355X (613 frames, G=28): 0: 7.16 ms, 1: 7.06, 2: 6.67 (default), 3: 7.97
     static const int variant = getenv("SSLAM_CONV_VARIANT") ? atoi(getenv("SSLAM_CONV_VARIANT")) : 2;
