@@ -40,10 +40,16 @@ __device__ __forceinline__ void gemm_bf16(const bf16 *tile, const unsigned char 
                                           f32x16 (&acc)[2][NT]) {
     constexpr int TILES = 4 * NT;   // N / 32
     const int r = lane & 31, h = lane >> 5;
-    const bf16x8 *bsrc = reinterpret_cast<const bf16x8 *>(w) + (wn * NT) * 64 + lane;
+    // buffer loads: descriptor over this layer's weights + 32-bit lane offset + SCALAR (k-step, tile) offset - no vector
+    // address arithmetic in the k loop (every non-MFMA instruction costs matrix-pipe issue time)
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(w), 0, KS * TILES * 1024, 0x00020000);
+    const int loff = ((wn * NT) * 64 + lane) * 16;
     const bf16 *A = tile + r * LDT + 8 * h;
     bf16x8 q0[NT], q1[NT], q2[NT];
-#define LOAD_B(dst, ks) _Pragma("unroll") for (int t = 0; t < NT; t++) dst[t] = bsrc[((ks) * TILES + t) * 64];
+#define LOAD_B(dst, ks)                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) dst[t] = __builtin_bit_cast(                    \
+        bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, ((ks) * TILES + t) * 1024, 0));
 #define STEP(cur, ks)                                                                              \
     {                                                                                              \
         const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(A + (ks) * 16);                        \
@@ -58,11 +64,17 @@ __device__ __forceinline__ void gemm_bf16(const bf16 *tile, const unsigned char 
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 3) {
         LOAD_B(q2, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
         STEP(q0, ks);
-        if (ks + 3 < KS) LOAD_B(q0, ks + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD_B(q0, min(ks + 3, KS - 1));      // unconditional (clamped): the compiler keeps an exact count of loads in flight
+        __builtin_amdgcn_sched_barrier(0);
         STEP(q1, ks + 1);
-        if (ks + 4 < KS) LOAD_B(q1, ks + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD_B(q1, min(ks + 4, KS - 1));
+        __builtin_amdgcn_sched_barrier(0);
         STEP(q2, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #undef LOAD_B
 #undef STEP

@@ -47,37 +47,42 @@ __global__ __launch_bounds__(64 * WM * WN) void selector_bf16_kernel(const bf16 
     }
     const long long m0 = (long long)tile * BM;
 
-    // piece i of this thread: row = tid / 16 + ROWSTEP * i, 16-B column a_pc = tid % 16 (the same for every piece)
+    // piece i of this thread: row = tid / 16 + ROWSTEP * i, 16-B column a_pc = tid % 16 (the same for every piece).
+    // Buffer loads (see selector.hip): descriptor base + 32-bit lane offset of the row's own cell (+ the tap shift, one
+    // add) + SCALAR chunk offset; taps outside the grid are zeroed at STORE_STAGE by a precomputed 9-bit validity mask.
     const int a_row0 = tid / (BKB / 8), a_pc = tid % (BKB / 8);
-    int a_yx[A_ITEMS];                                     // y << 16 | x, or -1 for rows beyond n_rows
-    unsigned a_off[A_ITEMS];                               // element offset of (frame, cell 0, a_pc * 8)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 2u)), 0x00020000);
+    int a_voff[A_ITEMS], a_mask[A_ITEMS];
 #pragma unroll
     for (int i = 0; i < A_ITEMS; i++) {
         const long long m = m0 + a_row0 + ROWSTEP * i;
-        const bool ok = m < n_rows;
-        const long long mm = ok ? m : m0;                  // rows beyond n_rows: any readable address of the tile's frame
-        const int f = (int)(mm / cells), cell = (int)(mm % cells);
-        a_yx[i] = ok ? ((cell / G) << 16 | (cell % G)) : -1;
-        a_off[i] = (unsigned)((long long)f * cells * SSLAM_C + a_pc * 8 - (long long)(m0 / cells) * cells * SSLAM_C);
+        const bool okr = m < n_rows;
+        const long long mm = okr ? m : m0;
+        const int cell = (int)(mm % cells), y = cell / G, x = cell % G;
+        a_voff[i] = (int)((unsigned)mm * (SSLAM_C * 2u) + a_pc * 16u);
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            mk |= (okr && yy >= 0 && yy < G && xx >= 0 && xx < G) ? (1 << t) : 0;
+        }
+        a_mask[i] = mk;
     }
-    const bf16 *fbase = feat + (long long)(m0 / cells) * cells * SSLAM_C;   // frame of the tile's first row (uniform)
     u32x4 ra[A_ITEMS];
+    unsigned ra_keep[A_ITEMS];
 #define LOAD_STAGE(S)                                                                                        \
     {                                                                                                        \
         const int s_ = (S);                                                                                  \
         const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                      \
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;                                                        \
+        const int toff_ = ((tap / 3 - 1) * G + (tap % 3 - 1)) * (SSLAM_C * 2), soff_ = chunk * (BKB * 2);    \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                \
-            const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;                               \
-            const bool ok = a_yx[i] >= 0 && yy >= 0 && yy < G && xx >= 0 && xx < G;                          \
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(                                                \
-                fbase + a_off[i] + (ok ? (unsigned)((yy * G + xx) * SSLAM_C + chunk * BKB) : 0u));           \
-            ra[i] = v & (ok ? 0xffffffffu : 0u);                                                             \
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[i] + toff_, soff_, 0);                 \
+            ra_keep[i] = ((a_mask[i] >> tap) & 1) ? 0xffffffffu : 0u;                                        \
         }                                                                                                    \
     }
 #define STORE_STAGE(BUF)                                                                                     \
     _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++)                                                      \
-        *reinterpret_cast<u32x4 *>(smem + (BUF) * STAGE + (a_row0 + ROWSTEP * i) * LDB + a_pc * 8) = ra[i];
+        *reinterpret_cast<u32x4 *>(smem + (BUF) * STAGE + (a_row0 + ROWSTEP * i) * LDB + a_pc * 8) = ra[i] & ra_keep[i];
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -91,6 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN) void selector_bf16_kernel(const bf16 
     // B fragment (global k-step = stage*8 + ks, N tile t): 16 B per lane at ((kstep * (HS/32) + t) * 64 + lane)
     const bf16x8 *bsrc = reinterpret_cast<const bf16x8 *>(w1p) + (wn * 2) * 64 + lane;
     constexpr int GSTR = (HS / 32) * 64;           // bf16x8 elements per global k-step
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(w1p), 0, 9 * SSLAM_C * HS * 2, 0x00020000);
+    const int b_voff = ((wn * 2) * 64 + lane) * 16;
     bf16x8 bq[RING][2];
 #pragma unroll
     for (int i = 0; i < RING; i++) {
@@ -109,11 +116,9 @@ __global__ __launch_bounds__(64 * WM * WN) void selector_bf16_kernel(const bf16 
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) a[mi] = *reinterpret_cast<const bf16x8 *>(As + mi * 32 * LDB + ks * 16);
             const bf16x8 b0 = bq[ks % RING][0], b1v = bq[ks % RING][1];
-            const long long gn = (long long)s * KSB + ks + RING;
-            if (gn < (long long)NSTB * KSB) {
-                bq[ks % RING][0] = bsrc[gn * GSTR];
-                bq[ks % RING][1] = bsrc[gn * GSTR + 64];
-            }
+            const int gn = min(s * KSB + ks + RING, NSTB * KSB - 1);      // unconditional refill (clamped at the tail)
+            bq[ks % RING][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, gn * (GSTR * 16), 0));
+            bq[ks % RING][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, gn * (GSTR * 16) + 1024, 0));
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
                 acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b0, acc[mi][0], 0, 0, 0);
@@ -202,7 +207,7 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
     if (!feat_bf16 || !w1_packed_bf16 || !b1 || !w2 || !b2 || !sal || n_frames <= 0 || G <= 0) return SSLAM_E_INVALID;
     if (((uintptr_t)feat_bf16 | (uintptr_t)w1_packed_bf16) & 15) return SSLAM_E_INVALID;
     const long long rows = (long long)n_frames * G * G;
-    if (rows > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    if (rows * (long long)(SSLAM_C * 2) > 0xffffffffLL) return SSLAM_E_UNSUPPORTED;   // one buffer descriptor spans the bf16 feature map
     hipStream_t st = (hipStream_t)stream;
     if (hs == 256) {
         static const int variant = [] { const char *e = getenv("SSLAM_CONVBF_VARIANT"); return e ? atoi(e) : 2; }();   // measured: 0: 1.08 ms, 1: 1.28 ms, 2: 0.96 ms / 613 frames
