@@ -87,14 +87,15 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 
     float4 ra_lo[A_ITEMS], ra_hi[A_ITEMS], rb[B_ITEMS];
     bool ra_ok[A_ITEMS];
+    int ld_tap = 0, ld_dy = -1, ld_dx = -1, ld_chunk = 0;      // the stage LOAD_STAGE fetches next (stages are fetched in order)
 
 #define LOAD_STAGE(S)                                                                                              \
     {                                                                                                              \
         const int s_ = (S);                                                                                        \
-        const int chunk = s_ / 9, tap = s_ - chunk * 9;                                                            \
+        const int chunk = ld_chunk, tap = ld_tap;       /* == s_ / 9, s_ % 9: carried incrementally (scalar ALU) */      \
         /* the tap shift can be negative and a buffer's scalar offset is unsigned: it goes into the lane offset (one  */ \
         /* add; a wrapped / too large result fails the range check and reads zeros), the chunk into the scalar part */ \
-        const int toff_ = ((tap / 3 - 1) * G + (tap % 3 - 1)) * (SSLAM_C * 4), soff_ = chunk * (BK * 4);             \
+        const int toff_ = (ld_dy * G + ld_dx) * (SSLAM_C * 4), soff_ = chunk * (BK * 4);                             \
         _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                      \
             const int vt_ = a_voff[i] + toff_;                                                                     \
             ra_lo[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, vt_, soff_, 0));             \
@@ -105,6 +106,10 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
             const float4 *wp = reinterpret_cast<const float4 *>(w1p + (long long)s_ * HS * BK);                    \
             _Pragma("unroll") for (int i = 0; i < B_ITEMS; i++) rb[i] = wp[tid + 512 * i];                         \
         }                                                                                                          \
+        /* advance (tap, dy, dx, chunk) to the stage after s_ */                                                   \
+        ld_tap++; ld_dx++;                                                                                         \
+        if (ld_dx == 2) { ld_dx = -1; ld_dy++; }                                                                   \
+        if (ld_tap == 9) { ld_tap = 0; ld_dy = -1; ld_chunk++; }                                                   \
     }
 #define STORE_STAGE(BUF)                                                                                           \
     {                                                                                                              \
