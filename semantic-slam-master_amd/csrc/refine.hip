@@ -172,6 +172,25 @@ __device__ __forceinline__ void layernorm_rows(float *H, const float *__restrict
     }
 }
 
+// Optional phase timers (build with -DSSLAM_CLOCK_PROBE, read with tools/clock_probe.py): wave 0 of the first 4096 workgroups
+// records its lifetime and the shader-clock cycles it spent in the gather, the GEMM loops, the LayerNorm calls, the tile
+// stores and waiting at barriers.  Compiled out of the product build.
+#ifdef SSLAM_CLOCK_PROBE
+__device__ unsigned long long g_probe_refine[8 * 4096];
+#define PROBE_BEGIN() const unsigned long long pr_t0 = clock64(); unsigned long long pr_q = 0, pr_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PROBE(slot, stmt) { pr_q = clock64(); stmt; pr_acc[slot] += clock64() - pr_q; }
+#define PROBE_END()                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                            \
+        g_probe_refine[8 * blockIdx.x] = clock64() - pr_t0;                                                 \
+        for (int i_ = 0; i_ < 6; i_++) g_probe_refine[8 * blockIdx.x + 1 + i_] = pr_acc[i_];                \
+    }
+#else
+#define PROBE_BEGIN()
+#define PROBE(slot, stmt) { stmt; }
+#define PROBE_END()
+#endif
+enum { PR_GATHER = 0, PR_GEMM = 1, PR_LN = 2, PR_STORE = 3, PR_BARRIER = 4 };
+
 __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(const float *__restrict__ feat, int G,
                                                              const float *__restrict__ kp_xy, int K,
                                                              const float *__restrict__ x_in, long long rows,
@@ -179,6 +198,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float *H = smem, *scratch = smem + H_FLOATS;
     const int tid = threadIdx.x;
+    PROBE_BEGIN();
     // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD one contiguous range of row tiles so that the ~8
     // tiles gathering from one frame's feature map share that XCD's L2 instead of fetching the frame into all eight
     long long R0;
@@ -220,34 +240,37 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
             }
         }
     }
-    __syncthreads();
+#ifdef SSLAM_CLOCK_PROBE
+    pr_acc[PR_GATHER] = clock64() - pr_t0;
+#endif
+    PROBE(PR_BARRIER, __syncthreads();)
 
     // ---- input_proj + ReLU (descriptor_refiner.py:76) -----------------------------------------------------------
     f32x16 X[3], acc[3];
-    gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);
+    PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);)
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int e = 0; e < 16; e++) X[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
-    __syncthreads();            // every wave has finished reading the tile
-    store_tile<3>(H, tid, X);
-    __syncthreads();
+    PROBE(PR_BARRIER, __syncthreads();)            // every wave has finished reading the tile
+    PROBE(PR_STORE, store_tile<3>(H, tid, X);)
+    PROBE(PR_BARRIER, __syncthreads();)
 
     // ---- residual blocks (descriptor_refiner.py:108-126) --------------------------------------------------------
     for (int b = 0; b < L.n_blocks; b++) {
-        layernorm_rows(H, pk + L.blk[b][0], pk + L.blk[b][1], tid);
-        __syncthreads();
-        gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);
+        PROBE(PR_LN, layernorm_rows(H, pk + L.blk[b][0], pk + L.blk[b][1], tid);)
+        PROBE(PR_BARRIER, __syncthreads();)
+        PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);)
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
-        __syncthreads();
-        store_tile<3>(H, tid, acc);
-        __syncthreads();
-        layernorm_rows(H, pk + L.blk[b][4], pk + L.blk[b][5], tid);
-        __syncthreads();
-        gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);
+        PROBE(PR_BARRIER, __syncthreads();)
+        PROBE(PR_STORE, store_tile<3>(H, tid, acc);)
+        PROBE(PR_BARRIER, __syncthreads();)
+        PROBE(PR_LN, layernorm_rows(H, pk + L.blk[b][4], pk + L.blk[b][5], tid);)
+        PROBE(PR_BARRIER, __syncthreads();)
+        PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);)
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -255,14 +278,14 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
                 const float v = acc[t][e] + X[t][e];
                 X[t][e] = v > 0.0f ? v : 0.0f;
             }
-        __syncthreads();
-        store_tile<3>(H, tid, X);
-        __syncthreads();
+        PROBE(PR_BARRIER, __syncthreads();)
+        PROBE(PR_STORE, store_tile<3>(H, tid, X);)
+        PROBE(PR_BARRIER, __syncthreads();)
     }
 
     // ---- output_proj + L2 normalise (:83-86; F.normalize eps 1e-12) --------------------------------------------
     f32x16 o[1];
-    gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);
+    PROBE(PR_GEMM, gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);)
     {
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
         float *part = scratch;  // [64 rows][4 waves]
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
             const float t = bfly32(o[0][e] * o[0][e]);
             if (r == 0) part[(wm * 32 + crow(e, h)) * 4 + wn] = t;
         }
-        __syncthreads();
+        PROBE(PR_BARRIER, __syncthreads();)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int row = wm * 32 + crow(e, h);
@@ -281,6 +304,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
             if (R0 + row < rows) desc[(R0 + row) * SSLAM_D + wn * 32 + r] = o[0][e] / den;
         }
     }
+    PROBE_END();
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ feat, int G, const float *__restrict__ kp_xy,
@@ -379,3 +403,9 @@ extern "C" int sslam_gather(const float *feat, int n_frames, int G, const float 
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }
+
+#ifdef SSLAM_CLOCK_PROBE
+extern "C" int sslam_probe_refine(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe_refine), sizeof(unsigned long long) * 8 * 4096) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -1,4 +1,10 @@
-"""Phase timing inside the MLP workgroups (needs a probe build of the library in place): see DESIGN.md section 9."""
+#!/usr/bin/env python3
+"""Phase timing inside the descriptor-MLP workgroups.  Needs the probe build of the kernel:
+
+    make -C semantic-slam-master_amd/csrc clean all EXTRA=-DSSLAM_CLOCK_PROBE && python tools/clock_probe.py
+    make -C semantic-slam-master_amd/csrc clean all        # back to the product build
+
+Prints, for wave 0 of the first 4096 workgroups, the mean lifetime and the shader-clock cycles spent per phase."""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,13 +13,17 @@ for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROO
 import synth
 from sslam_amd import lib
 from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+L = lib.lib()
+if not hasattr(L, "sslam_probe_refine"):
+    sys.exit("libsslam_hip.so was not built with -DSSLAM_CLOCK_PROBE")
 pipe = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0))
 toks = torch.randn(613, 789, 384, device="cuda") * 3 + 0.5
 for _ in range(3):
     pipe.extract(toks)
 torch.cuda.synchronize()
-L = lib.lib()
-buf = np.zeros(2 * 4096, np.uint64)
-L.sslam_probe_refine(ctypes.c_void_p(buf.ctypes.data))
-a, b = buf[0::2], buf[1::2]
-print("gather", np.mean((a >> np.uint64(32)).astype(np.float64)), "store_tile x5", np.mean((a & np.uint64(0xffffffff)).astype(np.float64)), "layernorm x4", np.mean(b.astype(np.float64)))
+buf = np.zeros(8 * 4096, np.uint64)
+assert L.sslam_probe_refine(ctypes.c_void_p(buf.ctypes.data)) == 0
+t = buf.reshape(4096, 8).astype(np.float64)
+names = ["lifetime", "gather", "gemm loops (6)", "layernorm (4)", "tile stores (5)", "barriers"]
+for i, n in enumerate(names):
+    print(f"{n:16s} {t[:, i].mean():10.0f} cycles  ({100 * t[:, i].mean() / t[:, 0].mean():5.1f} %)")
