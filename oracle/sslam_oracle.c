@@ -472,28 +472,41 @@ void ora_gather(const float *feat, int n_frames, int G, const float *kp_xy, int 
 
 /* ------------------------------------------------------------------------------------------------------
  * A7  descriptor MLP (descriptor_refiner.py:58-126)
- *   LayerNorm over 384: 48 partials of 8 consecutive elements (sequential), placed in a 64-slot array padded
- *   with zeros, butterfly64 -> sum; mean = sum/384; same on fmaf(d,d,.) for the variance; rstd = 1/sqrtf(var+eps);
- *   y = fmaf((x-mean)*rstd, gamma, beta).
- *   L2 normalise over 128 (F.normalize, eps 1e-12): p = v*v; T_w = butterfly32 over columns 32w..32w+31;
- *   ss = ((T_0+T_1)+T_2)+T_3; out = v / max(sqrtf(ss), 1e-12).
+ *   Row reductions follow the accumulator layout of the GPU kernel, which evaluates the products TRANSPOSED (a lane owns one
+ *   activation row; 4 waves x 96 columns; per wave two half-waves h, each holding columns slab + 32t + crow(e,h),
+ *   crow(e,h) = (e&3) + 8(e>>2) + 4h, t = 0..2, e = 0..15):
+ *     P[w][h] = sequential sum over (t, e) from 0;  W[w] = P[w][0] + P[w][1];  total = ((W0 + W1) + W2) + W3.
+ *   LayerNorm over 384: mean = total(x) / 384; variance likewise on fmaf(d, d, .) with d = x - mean;
+ *   rstd = 1/sqrtf(var + eps); y = fmaf((x - mean) * rstd, gamma, beta).
+ *   L2 normalise over 128 (F.normalize, eps 1e-12): 4 waves x 32 columns (t = 0 only), fmaf(v, v, .) chains, same tree;
+ *   out = v / max(sqrtf(total), 1e-12).
  * ---------------------------------------------------------------------------------------------------- */
+static inline int crow_(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+/* ((W0 + W1) + W2) + W3 over `tiles` 32-column tiles per wave; mode 0: sum x, 1: sum (x - mean)^2, 2: sum x^2 */
+static float slab_total(const float *x, int tiles, float mean, int mode) {
+    float W[4];
+    for (int w = 0; w < 4; w++) {
+        float P[2];
+        for (int h = 0; h < 2; h++) {
+            float s = 0.0f;
+            for (int t = 0; t < tiles; t++)
+                for (int e = 0; e < 16; e++) {
+                    const float v = x[w * 32 * tiles + t * 32 + crow_(e, h)];
+                    if (mode == 0) s = s + v;
+                    else if (mode == 1) { const float d = v - mean; s = fmaf(d, d, s); }
+                    else s = fmaf(v, v, s);
+                }
+            P[h] = s;
+        }
+        W[w] = P[0] + P[1];
+    }
+    return ((W[0] + W[1]) + W[2]) + W[3];
+}
+
 static void layernorm384(const float *x, const float *g, const float *b, float *y) {
-    float a[64];
-    for (int j = 0; j < 64; j++) a[j] = 0.0f;
-    for (int j = 0; j < 48; j++) {
-        float s = x[8 * j];
-        for (int i = 1; i < 8; i++) s = s + x[8 * j + i];
-        a[j] = s;
-    }
-    const float mean = butterfly(a, 64) / 384.0f;
-    for (int j = 0; j < 64; j++) a[j] = 0.0f;
-    for (int j = 0; j < 48; j++) {
-        float s = 0.0f;
-        for (int i = 0; i < 8; i++) { const float d = x[8 * j + i] - mean; s = fmaf(d, d, s); }
-        a[j] = s;
-    }
-    const float var = butterfly(a, 64) / 384.0f;
+    const float mean = slab_total(x, 3, 0.0f, 0) / 384.0f;
+    const float var = slab_total(x, 3, mean, 1) / 384.0f;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     for (int c = 0; c < 384; c++) y[c] = fmaf((x[c] - mean) * rstd, g[c], b[c]);
 }
@@ -539,13 +552,7 @@ void ora_refine(const float *x, int rows, const float *const *w, int n_blocks, i
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < rows; r++) {
         float *v = desc + (size_t)r * d_out;
-        float ss = 0.0f;
-        for (int wv = 0; wv < d_out / 32; wv++) {
-            float q[32];
-            for (int c = 0; c < 32; c++) q[c] = v[32 * wv + c] * v[32 * wv + c];
-            const float T = butterfly(q, 32);
-            ss = (wv == 0) ? T : ss + T;
-        }
+        const float ss = slab_total(v, d_out / 128, 0.0f, 2);
         const float den = fmaxf(sqrtf(ss), 1e-12f);
         for (int c = 0; c < d_out; c++) v[c] = v[c] / den;
     }

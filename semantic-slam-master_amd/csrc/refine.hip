@@ -1,15 +1,18 @@
-// refine.hip - A6 + A7: bilinear feature gather and the descriptor MLP, fused per 64-row tile.
+// refine.hip - A6 + A7: bilinear feature gather and the descriptor MLP, fused per 32-row tile.
 // Replaces DinoBackbone.extract_at_keypoints (reference semantic-slam/models/dino_backbone.py:114-152) and
 // DescriptorRefiner.forward / ResidualBlock.forward (semantic-slam/models/descriptor_refiner.py:58-126).
 //
-// One workgroup (8 waves) owns 64 keypoint rows for the WHOLE chain: gather -> input_proj+ReLU -> n_blocks x
-// {LN, fc1, ReLU, LN, fc2, +identity, ReLU} -> output_proj -> L2 normalise.  The 64x384 activation tile lives in LDS
-// (KP8 order, 388-float rows) and is the MFMA A operand directly; the residual identity stays in registers in the
-// MFMA C layout (each wave keeps the same 32x96 output sub-tile in every layer).  The pre-packed weights (3.17 MB,
-// L2-resident, shared by all workgroups) are NOT staged through LDS: they are stored in MFMA-fragment order
-// ([k/8][n][8 floats KP8]), so a wave's B fragment is one fully coalesced 1 KB global load per tile, prefetched two
-// k-groups ahead into registers.  A layer's GEMM therefore has no barrier at all - waves drift freely and keep the
-// matrix pipe busy; barriers only separate the layers (activation tile hand-over).
+// One workgroup (4 waves; three are co-resident per CU) owns 32 keypoint rows for the WHOLE chain: gather ->
+// input_proj+ReLU -> n_blocks x {LN, fc1, ReLU, LN, fc2, +identity, ReLU} -> output_proj -> L2 normalise.  The 32x384
+// activation tile lives in LDS (KP8 order, 388-float rows).  The products are evaluated TRANSPOSED: the weight
+// fragment is the MFMA A operand and the activation rows the B operand, so a lane's accumulators hold ONE activation row
+// (96 of its columns per wave).  ReLU, the residual identity and LayerNorm then work on registers: row statistics are
+// lane-local sums, one xor-32 shuffle and a 4-wave exchange through LDS; the tile is written once per layer in 8-byte
+// pairs.  (The earlier row-per-wave LayerNorm on the LDS tile cost ~1 000 instructions per call, and every instruction
+// a wave issues besides its MFMAs takes issue time from the matrix pipe it shares - DESIGN.md section 9.)
+// The pre-packed weights (3.17 MB, L2-resident, shared by all workgroups) are NOT staged through LDS: they are stored in
+// MFMA-fragment order ([k/8][n][8 floats KP8]) and fetched by buffer loads with scalar (layer, k-group, tile) offsets,
+// 1 KB coalesced per wave-instruction, two k-groups ahead.  A layer's GEMM has no barrier.
 // All contractions are v_mfma_f32_32x32x2_f32 chains in increasing k from the bias: bit-identical to the oracle.
 //
 // Roofline: MFMA-bound, 1 572 864 FLOP per row (786.4 MFLOP per 500-keypoint frame) against 1.5 KB in / 0.5 KB out.
@@ -29,7 +32,7 @@ constexpr int HID = SSLAM_HID;      // 384
 constexpr int LDH = HID + 4;        // activation row stride (floats)
 constexpr int NKG = HID / 8;        // 48 k-groups of 8 per layer
 constexpr int H_FLOATS = RM * LDH;
-constexpr int SCRATCH_FLOATS = RM * 4;
+constexpr int SCRATCH_FLOATS = 256;     // two [4][32] row-statistic exchange buffers
 constexpr int SMEM_FLOATS = H_FLOATS + SCRATCH_FLOATS;   // 100 352 B
 
 struct RefArgs {
@@ -46,12 +49,17 @@ __device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t 
                                          int tid, f32x16 (&acc)[NT]) {
     constexpr int N = 128 * NT;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+    // TRANSPOSED product: the weight fragment is the MFMA A operand and the activation row the B operand, so the
+    // accumulator of lane (r, h) holds activation row m = r and output columns n = slab + 32t + crow(e, h) (runs of
+    // four consecutive n).  The fma chain of every output is unchanged (a*b commutes, k ascending from the bias).
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const float bv = bias[wn * 32 * NT + t * 32 + r];
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[t][e] = bv;
-    }
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + wn * 32 * NT + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[t][4 * q + i] = bv[i];
+        }
     // lane's B fragment of k-group g, tile t: 16 B at ((g*N + n)*8 + 4h) floats, n = wn*32*NT + t*32 + r.  Buffer loads:
     // address = descriptor base + 32-bit lane offset (constant) + SCALAR offset of (layer, k-group, tile), so the k loop
     // carries no vector address arithmetic at all - every non-MFMA instruction costs matrix-pipe issue time
@@ -66,7 +74,7 @@ __device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t 
         const f32x4 a = an;                                                           \
         an = *reinterpret_cast<const f32x4 *>(A + 8 * (((g) + 1) < NKG ? (g) + 1 : (g))); /* next k-group's A */ \
         _Pragma("unroll") for (int st = 0; st < 4; st++)                              \
-            _Pragma("unroll") for (int t = 0; t < NT; t++) acc[t] = mfma32(a[st], cur[t][st], acc[t]); \
+            _Pragma("unroll") for (int t = 0; t < NT; t++) acc[t] = mfma32(cur[t][st], a[st], acc[t]); \
     }
     LOAD_B(b0, 0);
     LOAD_B(b1, 1);
@@ -94,82 +102,67 @@ __device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t 
 #undef STEP
 }
 
-// write this wave's C-layout tiles back into the activation tile (KP8 positions)
-template <int NT>
-__device__ __forceinline__ void store_tile(float *H, int tid, const f32x16 (&v)[NT]) {
-    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+// this wave's 32 rows x 96 columns (transposed accumulators) -> activation tile (KP8 positions): the four consecutive
+// columns of an accumulator quad land as two 8-byte pairs
+__device__ __forceinline__ void store_rows(float *H, int tid, const f32x16 (&v)[3]) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
+    float *row = H + r * LDH + wn * 96 + 2 * h;
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int col = kp8(wn * 32 * NT + t * 32 + r);
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) H[(wm * 32 + crow(e, h)) * LDH + col] = v[t][e];
-    }
+        for (int q = 0; q < 4; q++) {
+            float *g = row + t * 32 + 8 * q;
+            *reinterpret_cast<float2 *>(g) = make_float2(v[t][4 * q], v[t][4 * q + 2]);
+            *reinterpret_cast<float2 *>(g + 4) = make_float2(v[t][4 * q + 1], v[t][4 * q + 3]);
+        }
 }
 
-// LayerNorm(384) in place on the 64 rows (wave w: rows 8w..8w+7; lane j < 48: elements 8j..8j+7); canonical order:
-// 8 sequential adds per lane, 64-lane butterfly (lanes >= 48 hold 0), two passes (oracle layernorm384)
-__device__ __forceinline__ void layernorm_rows(float *H, const float *__restrict__ gam, const float *__restrict__ bet,
-                                               int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool act = lane < 48;
-    const int j = act ? lane : 0;
-    float gm[8], bt[8];
-    {
-        const float4 g0 = *reinterpret_cast<const float4 *>(gam + 8 * j), g1 = *reinterpret_cast<const float4 *>(gam + 8 * j + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(bet + 8 * j), b1 = *reinterpret_cast<const float4 *>(bet + 8 * j + 4);
-        gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
-        bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
-    }
-    // All 8 rows of the wave go through every butterfly step TOGETHER: the 12 cross-lane steps per row are LDS-path
-    // round trips (ds_bpermute, several hundred cycles each while the other waves stream MFMA operands), and row by row
-    // they added up to 96 serial round trips per call - a quarter of the workgroup's lifetime.  Per row the operations
-    // and their order are unchanged (oracle layernorm384).
-    constexpr int NR = RM / (NTHR / 64);      // rows per wave
-    float x[NR][8], s[NR];
+// lane-local partial p of one row statistic -> its total over the row's 384 (or 128) columns, in the canonical tree of the
+// oracle (slab_total): the two half-waves of a wave, then the four waves in order.  `part` is a [4][32] LDS array; the
+// caller alternates between two of them so that consecutive reductions need no extra barrier.
+__device__ __forceinline__ float row_total(float p, float *part, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
+    p = p + __shfl_xor(p, 32);
+    if (h == 0) part[wn * 32 + r] = p;
+    __syncthreads();
+    return ((part[r] + part[32 + r]) + part[64 + r]) + part[96 + r];
+}
+
+// LayerNorm(384) of the wave's transposed accumulators (row m = r per lane), written to the activation tile as the next
+// GEMM's operand; v itself (the residual identity, where it is one) stays untouched in registers.  Oracle: layernorm384.
+__device__ __forceinline__ void layernorm_store(float *H, float *part0, float *part1, const float *__restrict__ gam,
+                                                const float *__restrict__ bet, int tid, const f32x16 (&v)[3]) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
+    float s = 0.0f;
 #pragma unroll
-    for (int rr = 0; rr < NR; rr++) {
-        const float *p = H + (wave * NR + rr) * LDH + 8 * j;
-        const float4 ev = *reinterpret_cast<const float4 *>(p), od = *reinterpret_cast<const float4 *>(p + 4);
-        x[rr][0] = ev.x; x[rr][1] = od.x; x[rr][2] = ev.y; x[rr][3] = od.y;
-        x[rr][4] = ev.z; x[rr][5] = od.z; x[rr][6] = ev.w; x[rr][7] = od.w;
-        float t = x[rr][0];
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int i = 1; i < 8; i++) t = t + x[rr][i];
-        s[rr] = act ? t : 0.0f;
-    }
+        for (int e = 0; e < 16; e++) s = s + v[t][e];
+    const float mean = row_total(s, part0, tid) / 384.0f;
+    float q = 0.0f;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) s[rr] = s[rr] + __shfl_xor(s[rr], m);
-    float mean[NR];
-#pragma unroll
-    for (int rr = 0; rr < NR; rr++) {
-        mean[rr] = s[rr] / 384.0f;
-        float s2 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float d = x[rr][i] - mean[rr];
-            s2 = __builtin_fmaf(d, d, s2);
+        for (int e = 0; e < 16; e++) {
+            const float d = v[t][e] - mean;
+            q = __builtin_fmaf(d, d, q);
         }
-        s[rr] = act ? s2 : 0.0f;
-    }
+    const float var = row_total(q, part1, tid) / 384.0f;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float *row = H + r * LDH + wn * 96 + 2 * h;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) s[rr] = s[rr] + __shfl_xor(s[rr], m);
+        for (int qd = 0; qd < 4; qd++) {
+            const int n0 = wn * 96 + t * 32 + 8 * qd + 4 * h;
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gam + n0), b4 = *reinterpret_cast<const f32x4 *>(bet + n0);
+            float y[4];
 #pragma unroll
-    for (int rr = 0; rr < NR; rr++) {
-        const float var = s[rr] / 384.0f;
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        float y[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) y[i] = __builtin_fmaf((x[rr][i] - mean[rr]) * rstd, gm[i], bt[i]);
-        if (act) {
-            float *p = H + (wave * NR + rr) * LDH + 8 * j;
-            *reinterpret_cast<float4 *>(p) = make_float4(y[0], y[2], y[4], y[6]);
-            *reinterpret_cast<float4 *>(p + 4) = make_float4(y[1], y[3], y[5], y[7]);
+            for (int i = 0; i < 4; i++) y[i] = __builtin_fmaf((v[t][4 * qd + i] - mean) * rstd, g4[i], b4[i]);
+            float *g = row + t * 32 + 8 * qd;
+            *reinterpret_cast<float2 *>(g) = make_float2(y[0], y[2]);
+            *reinterpret_cast<float2 *>(g + 4) = make_float2(y[1], y[3]);
         }
-    }
 }
 
 // Optional phase timers (build with -DSSLAM_CLOCK_PROBE, read with tools/clock_probe.py): wave 0 of the first 4096 workgroups
@@ -246,29 +239,27 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     PROBE(PR_BARRIER, __syncthreads();)
 
     // ---- input_proj + ReLU (descriptor_refiner.py:76) -----------------------------------------------------------
+    // Hand-over between two GEMMs: every wave turns its accumulators into the next operand IN REGISTERS (ReLU, residual,
+    // LayerNorm with lane-local row statistics) and writes the tile once; the barriers inside row_total also order the
+    // tile accesses (all waves have left the GEMM that read the tile before anyone writes it).
+    float *part0 = scratch, *part1 = scratch + 128;
     f32x16 X[3], acc[3];
     PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);)
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int e = 0; e < 16; e++) X[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
-    PROBE(PR_BARRIER, __syncthreads();)            // every wave has finished reading the tile
-    PROBE(PR_STORE, store_tile<3>(H, tid, X);)
-    PROBE(PR_BARRIER, __syncthreads();)
 
     // ---- residual blocks (descriptor_refiner.py:108-126) --------------------------------------------------------
     for (int b = 0; b < L.n_blocks; b++) {
-        PROBE(PR_LN, layernorm_rows(H, pk + L.blk[b][0], pk + L.blk[b][1], tid);)
+        PROBE(PR_LN, layernorm_store(H, part0, part1, pk + L.blk[b][0], pk + L.blk[b][1], tid, X);)
         PROBE(PR_BARRIER, __syncthreads();)
         PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);)
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
-        PROBE(PR_BARRIER, __syncthreads();)
-        PROBE(PR_STORE, store_tile<3>(H, tid, acc);)
-        PROBE(PR_BARRIER, __syncthreads();)
-        PROBE(PR_LN, layernorm_rows(H, pk + L.blk[b][4], pk + L.blk[b][5], tid);)
+        PROBE(PR_LN, layernorm_store(H, part0, part1, pk + L.blk[b][4], pk + L.blk[b][5], tid, acc);)
         PROBE(PR_BARRIER, __syncthreads();)
         PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);)
 #pragma unroll
@@ -278,30 +269,28 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
                 const float v = acc[t][e] + X[t][e];
                 X[t][e] = v > 0.0f ? v : 0.0f;
             }
-        PROBE(PR_BARRIER, __syncthreads();)
-        PROBE(PR_STORE, store_tile<3>(H, tid, X);)
-        PROBE(PR_BARRIER, __syncthreads();)
     }
+    PROBE(PR_BARRIER, __syncthreads();)            // every wave has finished reading the tile
+    PROBE(PR_STORE, store_rows(H, tid, X);)
+    PROBE(PR_BARRIER, __syncthreads();)
 
     // ---- output_proj + L2 normalise (:83-86; F.normalize eps 1e-12) --------------------------------------------
     f32x16 o[1];
     PROBE(PR_GEMM, gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);)
     {
-        const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
-        float *part = scratch;  // [64 rows][4 waves]
+        const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
+        float ss = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const float t = bfly32(o[0][e] * o[0][e]);
-            if (r == 0) part[(wm * 32 + crow(e, h)) * 4 + wn] = t;
-        }
-        PROBE(PR_BARRIER, __syncthreads();)
+        for (int e = 0; e < 16; e++) ss = __builtin_fmaf(o[0][e], o[0][e], ss);
+        const float den = fmaxf(sqrtf(row_total(ss, part0, tid)), 1e-12f);
+        if (R0 + r < rows) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int row = wm * 32 + crow(e, h);
-            const float4 t = *reinterpret_cast<const float4 *>(part + row * 4);
-            const float ss = ((t.x + t.y) + t.z) + t.w;
-            const float den = fmaxf(sqrtf(ss), 1e-12f);
-            if (R0 + row < rows) desc[(R0 + row) * SSLAM_D + wn * 32 + r] = o[0][e] / den;
+            for (int q = 0; q < 4; q++) {
+                f32x4 w4;
+#pragma unroll
+                for (int i = 0; i < 4; i++) w4[i] = o[0][4 * q + i] / den;
+                *reinterpret_cast<f32x4 *>(desc + (R0 + r) * SSLAM_D + wn * 32 + 8 * q + 4 * h) = w4;
+            }
         }
     }
     PROBE_END();
