@@ -221,8 +221,11 @@ class SequencePipeline:
         n = tokens.shape[0]
         parts = []
         vit_in = None
-        for a in range(0, n, cfg.chunk_frames):
-            b = min(a + cfg.chunk_frames, n)
+        # one launch group = cfg.chunk_frames frames, but never more than one 32-bit buffer descriptor can span
+        # (the saliency CNN addresses the fp32 feature map through a single descriptor: < 4 GiB per launch)
+        step = max(1, min(cfg.chunk_frames, (2 ** 32 - 1) // (cfg.grid * cfg.grid * lib.C_FEAT * 4)))
+        for a in range(0, n, step):
+            b = min(a + step, n)
             img = None if images_u8 is None else images_u8[a:b]
             if with_preprocess and img is not None:
                 vit_in = self.preprocess(img)      # A0: would feed the ViT (A1, third-party)
