@@ -5,9 +5,13 @@
 
 namespace {
 
+// one all-zero feature row: a tap outside the grid (zero padding) reads it instead of being masked element by element
+// afterwards - 8 selects per keypoint instead of 32 per 8-channel chunk (every instruction a wave issues besides its
+// MFMAs takes issue time from the matrix pipe it shares with the other resident waves)
+__device__ float g_zero_row[SSLAM_C];
+
 struct Taps {
-    const float *src[4];   // always a readable address (clamped into the grid)
-    bool ok[4];            // false: the tap lies outside the grid and contributes 0 * weight (zero padding)
+    const float *src[4];   // the tap's feature row, or g_zero_row for a tap outside the grid
     float wt[4];
 };
 
@@ -25,18 +29,15 @@ __device__ __forceinline__ Taps make_taps(const float *feat_frame, int G, float 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int xs = xi + (k & 1), ys = yi + (k >> 1);
-        t.ok[k] = !(xs < 0 || xs >= G || ys < 0 || ys >= G);
+        const bool ok = !(xs < 0 || xs >= G || ys < 0 || ys >= G);
         const int xc = min(max(xs, 0), G - 1), yc = min(max(ys, 0), G - 1);
-        t.src[k] = feat_frame + ((long long)yc * G + xc) * SSLAM_C;
+        t.src[k] = ok ? feat_frame + ((long long)yc * G + xc) * SSLAM_C : g_zero_row;
     }
     return t;
 }
 
-// unconditional load + select: keeps the four tap loads of a chunk in flight together (no branch per tap)
 __device__ __forceinline__ float4 ld4(const Taps &t, int k, int off) {
-    const float4 v = *reinterpret_cast<const float4 *>(t.src[k] + off);
-    const bool ok = t.ok[k];
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    return *reinterpret_cast<const float4 *>(t.src[k] + off);
 }
 __device__ __forceinline__ float4 blend4(const Taps &t, int off) {
     const float4 a = ld4(t, 0, off), b = ld4(t, 1, off), c = ld4(t, 2, off), d = ld4(t, 3, off);
