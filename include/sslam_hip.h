@@ -7,8 +7,10 @@
  * stage; each cites the reference code it replaces (paths relative to the reference repo).
  *
  * Conventions (all entries):
- *   - every pointer is a CALLER-OWNED DEVICE pointer unless the name ends in _host; the library never allocates,
- *     frees or copies to the host;
+ *   - every pointer is a CALLER-OWNED DEVICE pointer unless the name ends in _host; the library never copies to
+ *     the host and allocates nothing, with ONE documented exception: the batched form of sslam_sim_argmax takes
+ *     n_pairs*n2*8 bytes of stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`, released on every
+ *     return path); pass SSLAM_M1_VARIANT=1 for the scratch-free form;
  *   - `stream` is a hipStream_t passed as void* (PyTorch: torch.cuda.current_stream().cuda_stream); calls only
  *     enqueue work - no synchronisation, no host read-back;
  *   - return value: SSLAM_OK or a negative SSLAM_E_* code; launch failures are reported via hipGetLastError;

@@ -293,12 +293,16 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
         }
         hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
                            desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys);
-        SSLAM_CHECK_LAUNCH();
-        const long long n = (long long)n_pairs * n2;
-        hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
-        SSLAM_CHECK_LAUNCH();
-        if (hipFreeAsync(keys, st) != hipSuccess) return SSLAM_E_LAUNCH;
-        return SSLAM_OK;
+        g_sslam_launches++;
+        bool ok = hipGetLastError() == hipSuccess;
+        if (ok) {
+            const long long n = (long long)n_pairs * n2;
+            hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
+            g_sslam_launches++;
+            ok = hipGetLastError() == hipSuccess;
+        }
+        if (hipFreeAsync(keys, st) != hipSuccess) ok = false;     // the scratch is released on the failure paths too
+        return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
     }
     const int nmax = n1 > n2 ? n1 : n2;
     hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(512), 0, st, desc1, stride1, n1,

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void select_keypoints_kernel(const float *__res
     };
     auto sorted_cell = [&](int pos) { return (int)(0xffffffffu - (unsigned)(keys[pos] & 0xffffffffu)); };
 
-    int st = 0;
+    int st = 0, filled = K;
     if (nv >= K) {
         // :120-128  top-K of the survivors above the threshold
         compact(n, 0, K, [&](int p) { return nmsv[sorted_cell(p)] > thr; }, sorted_cell,
@@ -205,13 +205,20 @@ __global__ __launch_bounds__(NT) void select_keypoints_kernel(const float *__res
             if (remaining > n) st = 1;
             const int m = min(remaining, n);
             for (int j = tid; j < m; j += NT) emit(nv + j, sorted_cell(j), key_val(keys[j]));
+            filled = nv + m;
         }
     } else {
         // :174-184  nothing above the threshold: top-K of the raw saliency
         if (K > n) st = 1;
         const int m = min(K, n);
         for (int j = tid; j < m; j += NT) emit(j, sorted_cell(j), key_val(keys[j]));
+        filled = m;
     }
+    // :186-199  fewer than K points (only when torch.topk would have raised, status = 1): repeat the best one.  The first
+    // slot holding the maximum score is the lowest-index cell of the global maximum in both branches (it is an NMS
+    // survivor above the threshold whenever any cell is), i.e. position 0 of the canonical order.
+    if (st)
+        for (int j = filled + tid; j < K; j += NT) emit(j, sorted_cell(0), key_val(keys[0]));
     if (tid == 0) status[f] = st;
 }
 

@@ -7,6 +7,8 @@ tensors it runs as ordinary torch ops on the same Parameters.
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -41,6 +43,7 @@ class DescriptorRefiner(nn.Module):
         self.output_proj = nn.Linear(hidden_dim, output_dim)
         self._packed = None
         self._packed_key = None
+        self._warned = False
         self._init_weights()
 
     def _init_weights(self):
@@ -59,11 +62,23 @@ class DescriptorRefiner(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def _hip_ok(self, x: torch.Tensor) -> bool:
+        """HIP path only for 384 -> 384 -> 128 (any other dims the reference accepts, descriptor_refiner.py:22-45, run
+        as eager torch ops) and when weights and input share a GPU."""
+        w_in, w_out = self.input_proj.weight, self.output_proj.weight
+        if not PackedRefiner.supported(w_in.shape[1], w_in.shape[0], w_out.shape[0], len(self.residual_blocks)):
+            if not self._warned:
+                warnings.warn(f"DescriptorRefiner: {w_in.shape[1]} -> {w_in.shape[0]} -> {w_out.shape[0]} is outside the HIP "
+                              f"kernel's shape (384 -> 384 -> 128); using the eager torch path")
+                self._warned = True
+            return False
+        return w_in.device == x.device
+
     def forward(self, dino_features: torch.Tensor) -> torch.Tensor:
         """(B, N, C) features at keypoints -> (B, N, output_dim) L2-normalised descriptors (descriptor_refiner.py:58-91)."""
         B, N, C = dino_features.shape
         needs_graph = torch.is_grad_enabled() and (dino_features.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if dino_features.is_cuda and not needs_graph:
+        if dino_features.is_cuda and not needs_graph and self._hip_ok(dino_features):
             pk = self._packed_weights()
             x = dino_features.detach().contiguous().float().reshape(B * N, C)
             return lib.refine(x, pk.packed, pk.n_blocks).reshape(B, N, self.output_dim)

@@ -24,8 +24,17 @@ from sslam_amd import lib
 
 class DinoBackbone(nn.Module):
     def __init__(self, model_name: str = "vit_small_patch16_dinov3.lvd1689m", input_size: int = 448, freeze: bool = True,
-                 dino: nn.Module | None = None):
+                 dino: nn.Module | None = None, vit_precision: str = "bf16"):
+        """The first three arguments are the reference's (dino_backbone.py:25-30).  `vit_precision` says how the frozen
+        in-repo ViT runs on a GPU under no_grad: "bf16" = the HIP ViT-S/16 (bf16 MFMA operands, fp32 accumulation and
+        fp32 LayerNorm / softmax / residual; tokens within rel 2.5e-2 / cos > 0.995 of the fp32 definition - keypoint
+        and match agreement with the fp32 path is MEASURED in tests/test_gpu_harness.py, it is not bit-exact), "fp32" =
+        the eager fp32 torch definition (what the reference's timm model computes).  Every entry point that needs
+        tokens (forward(), harness.SequenceMatcher) goes through forward_tokens(), so they agree with each other."""
         super().__init__()
+        if vit_precision not in ("bf16", "fp32"):
+            raise ValueError(f"vit_precision must be 'bf16' or 'fp32', got {vit_precision!r}")
+        self.vit_precision = vit_precision
         self.model_name = model_name
         self.input_size = input_size
         self.patch_size = 16
@@ -55,28 +64,34 @@ class DinoBackbone(nn.Module):
         return not next(self.dino.parameters()).requires_grad
 
     # -------------------------------------------------------------------------------------------- forward
-    def _hip_vit(self):
-        """HIP execution of the in-repo ViT definition (bf16 MFMA); rebuilt when the ViT's parameters change."""
+    def _hip_vit(self, images: torch.Tensor):
+        """HIP execution of the in-repo ViT definition (bf16 MFMA); rebuilt when the ViT's parameters change.  None
+        unless vit_precision == "bf16", the ViT is the in-repo definition, and its parameters live on the images' GPU
+        (a CPU-resident module with CUDA images takes the eager path, which raises torch's usual device error)."""
         from sslam_amd.vit import DinoV3ViT
         from sslam_amd.vit_hip import HipViT
-        if not isinstance(self.dino, DinoV3ViT):
+        if self.vit_precision != "bf16" or not isinstance(self.dino, DinoV3ViT) or not images.is_cuda:
             return None
         ps = list(self.dino.parameters())
+        if ps[0].device != images.device:
+            return None
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_hip_vit_obj", None) is None or self._hip_vit_key != key:
             self._hip_vit_obj, self._hip_vit_key = HipViT(self.dino, ps[0].device), key
         return self._hip_vit_obj
 
+    def forward_tokens(self, images: torch.Tensor) -> torch.Tensor:
+        """(B, 3, H, W) -> (B, 1 + 4 + N, C) final-LayerNormed ViT tokens: the call at dino_backbone.py:85."""
+        grad = self.training and not self._is_frozen()
+        hv = None if (grad and torch.is_grad_enabled()) else self._hip_vit(images)
+        if hv is not None:
+            return hv.forward_features(images)
+        with torch.set_grad_enabled(grad):
+            return self.dino.forward_features(images)
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         """(B, 3, H, W) -> (B, grid_h, grid_w, embed_dim) patch features (dino_backbone.py:70-108)."""
-        grad = self.training and not self._is_frozen()
-        hv = self._hip_vit() if (images.is_cuda and not (grad and torch.is_grad_enabled())) else None
-        if hv is not None:
-            features = hv.forward_features(images)          # HIP ViT-S/16 (tolerance-level parity, bf16 operands)
-        else:
-            with torch.set_grad_enabled(grad):
-                features = self.dino.forward_features(images)
-        return self.tokens_to_features(features)
+        return self.tokens_to_features(self.forward_tokens(images))
 
     def tokens_to_features(self, features: torch.Tensor) -> torch.Tensor:
         """The part of forward() after the ViT call: (B, 1 + 4 + N, C) tokens -> (B, grid_h, grid_w, C)."""

@@ -10,6 +10,7 @@ return conventions.  Execution:
 """
 from __future__ import annotations
 
+import warnings
 from typing import Tuple
 
 import torch
@@ -36,6 +37,7 @@ class KeypointSelector(nn.Module):
         )
         self._packed = None
         self._packed_key = None
+        self._warned = False
         self._init_weights()
 
     def _init_weights(self):
@@ -56,9 +58,21 @@ class KeypointSelector(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------------------------------------ API
+    def _hip_ok(self, x: torch.Tensor) -> bool:
+        """HIP path only for the shapes the kernels are built for and when weights and input share a GPU; any other
+        `hidden_dim` / `input_dim` the reference accepts (keypoint_selector.py:22-36) runs as eager torch ops."""
+        w = self.conv[0].weight
+        if not PackedSelector.supported(w.shape) or x.shape[-1] != lib.C_FEAT:
+            if not self._warned:
+                warnings.warn(f"KeypointSelector: Conv2d weight {tuple(w.shape)} is outside the HIP kernels' shapes "
+                              f"(384 -> 128 | 256); using the eager torch path")
+                self._warned = True
+            return False
+        return w.device == x.device      # mismatch: let the torch ops below raise their usual device error
+
     def forward(self, dino_features: torch.Tensor) -> torch.Tensor:
         """(B, H, W, C) patch features -> (B, H, W, 1) saliency in [0, 1]  (keypoint_selector.py:45-67)."""
-        if dino_features.is_cuda and not _needs_graph(self, dino_features):
+        if dino_features.is_cuda and not _needs_graph(self, dino_features) and self._hip_ok(dino_features):
             pk = self._packed_weights()
             x = dino_features.detach().contiguous().float()
             sal = lib.selector_saliency(x, pk.w1p, pk.b1, pk.w2, pk.b2, pk.hidden)

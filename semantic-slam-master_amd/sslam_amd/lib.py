@@ -114,14 +114,38 @@ def _check(rc: int, what: str):
         raise SslamHipError(f"{what}: {_ERR.get(rc, rc)}")
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def common_device(*tensors):
+    """The ONE CUDA device every tensor argument of a call lives on.  Raises ValueError for a CPU tensor or for tensors
+    on different GPUs (the reference's torch ops raise a device-mismatch error there; handing a device-1 pointer to a
+    device-0 stream would be a GPU memory fault instead)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError(f"libsslam_hip takes CUDA tensors only, got a tensor on {t.device}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensor arguments on different devices: {dev} and {t.device}")
+    if dev is None:
+        raise ValueError("no device tensor among the arguments")
+    return dev
+
+
+def _run(what: str, fn, tensors, *args):
+    """Call one C-ABI entry: all `tensors` must share a device; that device is made current for the call and the
+    launch goes to ITS current stream (not the process-wide current device's)."""
+    dev = common_device(*tensors)
+    with torch.cuda.device(dev):
+        _check(fn(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
 
 
 def _dp(t):
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError("device-resident contiguous tensor required")
     return C.c_void_p(t.data_ptr())
 
 
@@ -182,8 +206,8 @@ def preprocess_u8(img, size, tab_h, tab_v, out=None):
     if out is None:
         out = torch.empty((n, 3, size, size), dtype=torch.float32, device=img.device)
     (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
-    _check(lib().sslam_preprocess_u8(_dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(out), _stream()),
-           "preprocess_u8")
+    _run("preprocess_u8", lib().sslam_preprocess_u8, (img, bh, ch, bv, cv, out,),
+         _dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(out))
     return out
 
 
@@ -200,12 +224,14 @@ def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, ep
         var = torch.empty_like(mean)
     if bf16_copy:
         out_bf = torch.empty((n, cells, c), dtype=torch.bfloat16, device=tokens.device)
-        _check(lib().sslam_bn_tokens_bf16copy(_dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean),
+        _run("bn_tokens_bf16copy", lib().sslam_bn_tokens_bf16copy, (tokens, gamma, beta, run_mean, run_var, out, out_bf, mean, var,),
+         _dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean),
                                               _dp(run_var), int(bool(train)), C.c_float(eps), _dp(out), _dp(out_bf), _dp(mean),
-                                              _dp(var), _stream()), "bn_tokens_bf16copy")
+                                              _dp(var))
         return out, mean, var, out_bf
-    _check(lib().sslam_bn_tokens(_dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean), _dp(run_var),
-                                 int(bool(train)), C.c_float(eps), _dp(out), _dp(mean), _dp(var), _stream()), "bn_tokens")
+    _run("bn_tokens", lib().sslam_bn_tokens, (tokens, gamma, beta, run_mean, run_var, out, mean, var,),
+         _dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean), _dp(run_var),
+                                 int(bool(train)), C.c_float(eps), _dp(out), _dp(mean), _dp(var))
     return out, mean, var
 
 
@@ -213,8 +239,8 @@ def selector_saliency(feat, w1p, b1, w2, b2, hs, out=None):
     n, g = feat.shape[0], feat.shape[1]
     if out is None:
         out = torch.empty((n, g, g), dtype=torch.float32, device=feat.device)
-    _check(lib().sslam_selector_saliency(_dp(feat), n, g, _dp(w1p), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out), _stream()),
-           "selector_saliency")
+    _run("selector_saliency", lib().sslam_selector_saliency, (feat, w1p, b1, w2, b2, out,),
+         _dp(feat), n, g, _dp(w1p), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out))
     return out
 
 
@@ -232,7 +258,8 @@ def to_bf16(x, out=None):
     x = x.contiguous()
     if out is None:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _check(lib().sslam_f32_to_bf16(_dp(x), _dp(out), x.numel(), _stream()), "f32_to_bf16")
+    _run("f32_to_bf16", lib().sslam_f32_to_bf16, (x, out,),
+         _dp(x), _dp(out), x.numel())
     return out
 
 
@@ -240,8 +267,8 @@ def selector_saliency_bf16(feat_bf16, w1p_bf16, b1, w2, b2, hs, out=None):
     n, g = feat_bf16.shape[0], feat_bf16.shape[1]
     if out is None:
         out = torch.empty((n, g, g), dtype=torch.float32, device=feat_bf16.device)
-    _check(lib().sslam_selector_saliency_bf16(_dp(feat_bf16), n, g, _dp(w1p_bf16), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out),
-                                              _stream()), "selector_saliency_bf16")
+    _run("selector_saliency_bf16", lib().sslam_selector_saliency_bf16, (feat_bf16, w1p_bf16, b1, w2, b2, out,),
+         _dp(feat_bf16), n, g, _dp(w1p_bf16), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out))
     return out
 
 
@@ -253,8 +280,9 @@ def select_keypoints(sal, K, radius=2, pct=0.5, want_idx=True, want_pixel=True):
     idx = torch.empty((n, K), dtype=torch.int32, device=dev) if want_idx else None
     px = torch.empty((n, K, 2), dtype=torch.float32, device=dev) if want_pixel else None
     st = torch.empty((n,), dtype=torch.int32, device=dev)
-    _check(lib().sslam_select_keypoints(_dp(sal), n, g, K, radius, C.c_double(pct), _dp(kp), _dp(sc), _dp(idx), _dp(px),
-                                        _dp(st), _stream()), "select_keypoints")
+    _run("select_keypoints", lib().sslam_select_keypoints, (sal, kp, sc, idx, px, st,),
+         _dp(sal), n, g, K, radius, C.c_double(pct), _dp(kp), _dp(sc), _dp(idx), _dp(px),
+                                        _dp(st))
     return kp, sc, idx, px, st
 
 
@@ -263,7 +291,8 @@ def gather(feat, kp, out=None):
     K = kp.shape[1]
     if out is None:
         out = torch.empty((n, K, C_FEAT), dtype=torch.float32, device=feat.device)
-    _check(lib().sslam_gather(_dp(feat), n, g, _dp(kp), K, _dp(out), _stream()), "gather")
+    _run("gather", lib().sslam_gather, (feat, kp, out,),
+         _dp(feat), n, g, _dp(kp), K, _dp(out))
     return out
 
 
@@ -271,7 +300,8 @@ def refine(x, packed, n_blocks, out=None):
     rows = x.numel() // C_FEAT
     if out is None:
         out = torch.empty(x.shape[:-1] + (D_OUT,), dtype=torch.float32, device=x.device)
-    _check(lib().sslam_refine(_dp(x), rows, _dp(packed), n_blocks, _dp(out), _stream()), "refine")
+    _run("refine", lib().sslam_refine, (x, packed, out,),
+         _dp(x), rows, _dp(packed), n_blocks, _dp(out))
     return out
 
 
@@ -280,7 +310,8 @@ def gather_refine(feat, kp, packed, n_blocks, out=None):
     K = kp.shape[1]
     if out is None:
         out = torch.empty((n, K, D_OUT), dtype=torch.float32, device=feat.device)
-    _check(lib().sslam_gather_refine(_dp(feat), n, g, _dp(kp), K, _dp(packed), n_blocks, _dp(out), _stream()), "gather_refine")
+    _run("gather_refine", lib().sslam_gather_refine, (feat, kp, packed, out,),
+         _dp(feat), n, g, _dp(kp), K, _dp(packed), n_blocks, _dp(out))
     return out
 
 
@@ -289,8 +320,8 @@ def gather_refine_bf16(feat, kp, packed_bf16, n_blocks, out=None):
     K = kp.shape[1]
     if out is None:
         out = torch.empty((n, K, D_OUT), dtype=torch.float32, device=feat.device)
-    _check(lib().sslam_gather_refine_bf16(_dp(feat), n, g, _dp(kp), K, _dp(packed_bf16), n_blocks, _dp(out), _stream()),
-           "gather_refine_bf16")
+    _run("gather_refine_bf16", lib().sslam_gather_refine_bf16, (feat, kp, packed_bf16, out,),
+         _dp(feat), n, g, _dp(kp), K, _dp(packed_bf16), n_blocks, _dp(out))
     return out
 
 
@@ -298,7 +329,8 @@ def refine_bf16(x, packed_bf16, n_blocks, out=None):
     rows = x.shape[0]
     if out is None:
         out = torch.empty((rows, D_OUT), dtype=torch.float32, device=x.device)
-    _check(lib().sslam_refine_bf16(_dp(x), rows, _dp(packed_bf16), n_blocks, _dp(out), _stream()), "refine_bf16")
+    _run("refine_bf16", lib().sslam_refine_bf16, (x, packed_bf16, out,),
+         _dp(x), rows, _dp(packed_bf16), n_blocks, _dp(out))
     return out
 
 
@@ -308,8 +340,9 @@ def keypoint_intensity(img, size, tab_h, tab_v, kp_pixel, out=None):
     if out is None:
         out = torch.empty((n, K), dtype=torch.float32, device=img.device)
     (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
-    _check(lib().sslam_keypoint_intensity(_dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(kp_pixel), K,
-                                          _dp(out), _stream()), "keypoint_intensity")
+    _run("keypoint_intensity", lib().sslam_keypoint_intensity, (img, bh, ch, bv, cv, kp_pixel, out,),
+         _dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(kp_pixel), K,
+                                          _dp(out))
     return out
 
 
@@ -320,8 +353,9 @@ def sim_argmax(d1, stride1, n1, d2, stride2, n2, n_pairs, want_s21=False, want_s
     nn21 = torch.empty((n_pairs, n2), dtype=torch.int32, device=dev)
     s21 = torch.empty((n_pairs, n2), dtype=torch.float32, device=dev) if want_s21 else None
     sec = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev) if want_second else None
-    _check(lib().sslam_sim_argmax(C.c_void_p(d1.data_ptr()), stride1, n1, C.c_void_p(d2.data_ptr()), stride2, n2, n_pairs,
-                                  _dp(nn12), _dp(s12), _dp(nn21), _dp(s21), _dp(sec), _stream()), "sim_argmax")
+    _run("sim_argmax", lib().sslam_sim_argmax, (nn12, s12, nn21, s21, sec, d1, d2,),
+         C.c_void_p(d1.data_ptr()), stride1, n1, C.c_void_p(d2.data_ptr()), stride2, n2, n_pairs,
+                                  _dp(nn12), _dp(s12), _dp(nn21), _dp(s21), _dp(sec))
     return nn12, s12, nn21, s21, sec
 
 
@@ -331,12 +365,13 @@ def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in
     quality = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
     count = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     f = C.c_float
-    _check(lib().sslam_match_finalize(_dp(nn12), _dp(s12), _dp(nn21), n1, n2, n_pairs, C.c_void_p(sc1.data_ptr()), ss1,
+    _run("match_finalize", lib().sslam_match_finalize, (nn12, s12, nn21, matches, quality, count, sc1, sc2, in1, in2,),
+         _dp(nn12), _dp(s12), _dp(nn21), n1, n2, n_pairs, C.c_void_p(sc1.data_ptr()), ss1,
                                       C.c_void_p(sc2.data_ptr()), ss2,
                                       None if in1 is None else C.c_void_p(in1.data_ptr()),
                                       None if in2 is None else C.c_void_p(in2.data_ptr()),
                                       f(w_desc), f(w_sal), f(t_sal), f(t_sim), f(t_int), _dp(matches), _dp(quality),
-                                      _dp(count), _stream()), "match_finalize")
+                                      _dp(count))
     return matches, quality, count
 
 
@@ -352,6 +387,7 @@ def vit_forward(images_chw, weights: VitWeights, workspace, out=None):
     t = 5 + (size // 16) ** 2
     if out is None:
         out = torch.empty((n, t, C_FEAT), dtype=torch.float32, device=images_chw.device)
-    _check(lib().sslam_vit_forward(_dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(),
-                                   _dp(out), _stream()), "vit_forward")
+    _run("vit_forward", lib().sslam_vit_forward, (images_chw, workspace, out,),
+         _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(),
+                                   _dp(out))
     return out

@@ -19,6 +19,7 @@ from . import lib
 
 PATCH = 16
 N_PREFIX = 5   # CLS + 4 register tokens, dino_backbone.py:51,91
+MAX_PAIRS_PER_LAUNCH = 65535
 
 
 @dataclass
@@ -69,10 +70,16 @@ def refiner_weight_list(sd: dict):
 class PackedSelector:
     """Device-resident, kernel-order copy of a KeypointSelector state_dict."""
 
+    @staticmethod
+    def supported(conv0_weight_shape) -> bool:
+        """Shapes the saliency-CNN kernels are built for: Conv2d(384 -> 128 | 256, 3x3)."""
+        sh = tuple(conv0_weight_shape)
+        return len(sh) == 4 and sh[0] in (128, 256) and sh[1:] == (lib.C_FEAT, 3, 3)
+
     def __init__(self, sd: dict, device, bf16: bool = False):
         w1 = np.ascontiguousarray(_np(sd["conv.0.weight"]), np.float32)
         self.hidden = int(w1.shape[0])
-        if self.hidden not in (128, 256) or w1.shape[1:] != (lib.C_FEAT, 3, 3):
+        if not self.supported(w1.shape):
             raise lib.SslamHipError(f"selector shape {w1.shape} unsupported by the HIP kernels (hidden 128/256, C 384)")
         self.w1p = torch.from_numpy(lib.pack_conv3x3(w1)).to(device)
         self.b1 = torch.from_numpy(np.ascontiguousarray(_np(sd["conv.0.bias"]), np.float32)).to(device)
@@ -85,6 +92,11 @@ class PackedSelector:
 
 class PackedRefiner:
     """Device-resident packed DescriptorRefiner weights (one buffer, sslam_refiner_layout order)."""
+
+    @staticmethod
+    def supported(input_dim: int, hidden_dim: int, output_dim: int, n_blocks: int) -> bool:
+        """Shapes the fused descriptor-MLP kernel is built for: 384 -> 384 -> 128 with up to 8 residual blocks."""
+        return (input_dim, hidden_dim, output_dim) == (lib.C_FEAT, lib.HID, lib.D_OUT) and 0 <= n_blocks <= 8
 
     def __init__(self, sd: dict, device, bf16: bool = False):
         ws, self.n_blocks = refiner_weight_list(sd)
@@ -170,8 +182,24 @@ class SequencePipeline:
         shape = (tokens.shape[0], g, g, lib.C_FEAT)
         return (r[0].view(shape), r[3].view(shape)) if bf16_copy else r[0].view(shape)
 
+    def launch_group(self) -> int:
+        """Frames per launch group: cfg.chunk_frames, but never more than one 32-bit buffer descriptor can span (the
+        saliency CNN addresses the fp32 feature map through a single descriptor: < 4 GiB per launch)."""
+        return max(1, min(self.cfg.chunk_frames, (2 ** 32 - 1) // (self.cfg.grid ** 2 * lib.C_FEAT * 4)))
+
     def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
-        """A2..A9 for a batch of frames.  Returns device tensors; no host synchronisation."""
+        """A2..A9 for any number of frames (launch groups of `launch_group()` frames).  Returns device tensors; no host
+        synchronisation unless num_keypoints exceeds the number of grid cells (the only case `status` can be set)."""
+        n, step = tokens.shape[0], self.launch_group()
+        parts = [self._extract_group(tokens[a:a + step], None if images_u8 is None else images_u8[a:a + step])
+                 for a in range(0, n, step)]
+        out = parts[0] if len(parts) == 1 else {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        if self.cfg.num_keypoints > self.cfg.grid ** 2 and bool(out["status"].any()):
+            # torch.topk raises there in the reference (keypoint_selector.py:160 / :176, SURVEY H6)
+            raise RuntimeError("selected index k out of range")
+        return out
+
+    def _extract_group(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
         cfg, s = self.cfg, self.selector
         if self.bf16:
             feat, feat_bf = self.features(tokens, bf16_copy=True)
@@ -203,13 +231,18 @@ class SequencePipeline:
             return dict(matches=z((0, k, 2), dtype=torch.int64, device=desc.device),
                         quality=z((0, k), dtype=torch.float32, device=desc.device),
                         match_count=z((0,), dtype=torch.int32, device=desc.device))
-        nn12, s12, nn21, _, _ = lib.sim_argmax(desc, k * lib.D_OUT, k, desc[sp:], k * lib.D_OUT, k, n_pairs)
         use_int = cfg.use_intensity and intensity is not None
-        mt, q, cnt = lib.match_finalize(nn12, s12, nn21, k, k, n_pairs, scores, k, scores[sp:], k,
-                                        intensity if use_int else None, intensity[sp:] if use_int else None,
-                                        1.0 - cfg.saliency_weight, cfg.saliency_weight, cfg.min_saliency,
-                                        cfg.min_descriptor_sim, cfg.min_intensity)
-        return dict(matches=mt, quality=q, match_count=cnt, nn12=nn12, nn21=nn21, sim=s12)
+        parts = []
+        for a in range(0, n_pairs, MAX_PAIRS_PER_LAUNCH):       # the pair index is a 16-bit grid dimension
+            m = min(MAX_PAIRS_PER_LAUNCH, n_pairs - a)
+            d1, d2 = desc[a:a + m], desc[a + sp:a + sp + m]
+            nn12, s12, nn21, _, _ = lib.sim_argmax(d1, k * lib.D_OUT, k, d2, k * lib.D_OUT, k, m)
+            mt, q, cnt = lib.match_finalize(nn12, s12, nn21, k, k, m, scores[a:], k, scores[a + sp:], k,
+                                            intensity[a:] if use_int else None, intensity[a + sp:] if use_int else None,
+                                            1.0 - cfg.saliency_weight, cfg.saliency_weight, cfg.min_saliency,
+                                            cfg.min_descriptor_sim, cfg.min_intensity)
+            parts.append(dict(matches=mt, quality=q, match_count=cnt, nn12=nn12, nn21=nn21, sim=s12))
+        return parts[0] if len(parts) == 1 else {key: torch.cat([p[key] for p in parts]) for key in parts[0]}
 
     def run(self, images_u8: torch.Tensor | None, tokens: torch.Tensor | None = None, with_preprocess: bool = False) -> dict:
         """One pass of the hot path over a frame sequence: extract every frame once, match (i, i+spacing).
@@ -218,19 +251,12 @@ class SequencePipeline:
         if tokens is None:
             tokens = self.tokens_from_images(images_u8)
             with_preprocess = False
-        n = tokens.shape[0]
-        parts = []
         vit_in = None
-        # one launch group = cfg.chunk_frames frames, but never more than one 32-bit buffer descriptor can span
-        # (the saliency CNN addresses the fp32 feature map through a single descriptor: < 4 GiB per launch)
-        step = max(1, min(cfg.chunk_frames, (2 ** 32 - 1) // (cfg.grid * cfg.grid * lib.C_FEAT * 4)))
-        for a in range(0, n, step):
-            b = min(a + step, n)
-            img = None if images_u8 is None else images_u8[a:b]
-            if with_preprocess and img is not None:
-                vit_in = self.preprocess(img)      # A0: would feed the ViT (A1, third-party)
-            parts.append(self.extract(tokens[a:b], img))
-        out = {k: (torch.cat([p[k] for p in parts]) if len(parts) > 1 else parts[0][k]) for k in parts[0]}
+        if with_preprocess and images_u8 is not None:
+            step = self.launch_group()
+            for a in range(0, images_u8.shape[0], step):
+                vit_in = self.preprocess(images_u8[a:a + step])      # A0: would feed the ViT (A1)
+        out = dict(self.extract(tokens, images_u8))
         out.update(self.match(out["descriptors"], out["scores"], out.get("intensity")))
         if vit_in is not None:
             out["vit_input_last_chunk"] = vit_in

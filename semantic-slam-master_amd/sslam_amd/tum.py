@@ -54,6 +54,10 @@ class TUMSequence:
     def __len__(self):
         return len(self.rgb_files)
 
+    def n_pairs(self, frame_spacing: int = 1) -> int:
+        """What the reference's TUMDataset.__len__ returns (tum_dataset.py:119-120): frame pairs (i, i + spacing)."""
+        return max(0, len(self.rgb_files) - frame_spacing)
+
     def _load_groundtruth(self) -> np.ndarray:
         ts_gt, poses = [], []
         with open(self.gt_file) as f:

@@ -181,3 +181,35 @@ def wide_pair(seed: int):
     if seed % 2:
         kw = dict(kw, intensity1=i1, intensity2=i2)
     return d1, d2, s1, s2, kw
+
+
+def write_tum_sequence(root, n_rgb: int = 9, n_depth: int = 7, n_gt: int = 11) -> list:
+    """A tiny TUM RGB-D sequence directory (rgb/, depth/, groundtruth.txt) written deterministically, with the traits
+    that exercise data/tum_dataset.py:210-255: more rgb than depth files, several frames inside one whole second,
+    comment / short lines in groundtruth.txt, un-normalised quaternions, ground-truth stamps not aligned with frames.
+    Used by tests/golden/make_golden_tum.py (which runs the reference's TUMDataset on it) and by tests/test_tum_reader.py
+    (which runs sslam_amd.tum.TUMSequence on the same bytes).  Returns the rgb file names in creation order."""
+    import os
+
+    from PIL import Image
+    os.makedirs(os.path.join(root, "rgb"))
+    os.makedirs(os.path.join(root, "depth"))
+    rng = _rng(80_000)
+    names = []
+    for i in range(n_rgb):
+        # creation order is deliberately NOT the sorted order
+        k = (i * 4) % n_rgb
+        nm = f"{1305031452 + k // 3}.{(791720 + 333000 * k) % 1000000:06d}.png"
+        Image.fromarray(rng.integers(0, 255, (24, 32, 3), dtype=np.uint8)).save(os.path.join(root, "rgb", nm))
+        names.append(nm)
+    for i in range(n_depth):
+        nm = f"{1305031452 + i // 3}.{(800000 + 333000 * i) % 1000000:06d}.png"
+        Image.fromarray(rng.integers(2500, 25000, (24, 32)).astype(np.uint16)).save(os.path.join(root, "depth", nm))
+    with open(os.path.join(root, "groundtruth.txt"), "w") as f:
+        f.write("# ground truth trajectory\n# file: 'synthetic'\n# timestamp tx ty tz qx qy qz qw\nshort line 1 2\n\n")
+        for k in range(n_gt):
+            a = 0.13 * k
+            q = np.array([0.1 * np.sin(a), -0.2 * np.cos(a), np.sin(a), np.cos(a)]) * (1.0 + 0.05 * k)   # not unit norm
+            f.write(f"{1305031451.7 + 0.41 * k:.4f} {0.1 * k:.4f} {-0.05 * k:.4f} {1.0 + 0.01 * k:.4f} "
+                    f"{q[0]:.6f} {q[1]:.6f} {q[2]:.6f} {q[3]:.6f}\n")
+    return names

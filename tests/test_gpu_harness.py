@@ -1,0 +1,193 @@
+"""GPU tests of the reference-shaped harness (SURVEY §8f-3 and the glue around the hot path):
+
+* `StreamingSequence`: >= 25 frames, spacings (1, 5, 10, 15, 20) as at visualize_matches_sequence.py:369 - every pair's
+  matches / quality bit-exact vs the oracle's match_with_quality on the same descriptors, for one-shot and chunked
+  pushes alike; the reference's own pair set (process_spacing, :298-300) is a row subset of the result.
+* `SequenceMatcher.extract(path)`: PNG on disk -> PIL decode -> HIP A0 -> ViT -> A2..A9, the reference's dict keys and
+  dtypes (visualize_matches_sequence.py:97-104), values vs the oracle chain on the same tokens.
+* ViT precision: keypoint-set and match agreement of the bf16 HIP ViT path against the fp32 definition (reported and
+  bounded - it is NOT bit-exact and never claimed to be).
+* Drop-in shape fallback: KeypointSelector(384, 64) / DescriptorRefiner(hidden 256) on cuda run the eager path.
+"""
+import numpy as np
+import pytest
+
+import synth
+from oracle import ora
+
+pytestmark = pytest.mark.gpu
+
+SPACINGS = (1, 5, 10, 15, 20)
+CLI = dict(saliency_weight=0.3, min_saliency=0.5, min_descriptor_sim=0.7, min_intensity=0.15)   # :381-388
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def pipe(T):
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    return SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda")
+
+
+def _oracle_pair(fr, i, j):
+    return ora.match_with_quality(fr["descriptors"][i], fr["descriptors"][j], fr["scores"][i], fr["scores"][j],
+                                  CLI["saliency_weight"], CLI["min_saliency"], CLI["min_descriptor_sim"],
+                                  fr["intensity"][i], fr["intensity"][j], CLI["min_intensity"])
+
+
+def _check_spacing(res, s, n, fr):
+    mm = {k: v.cpu().numpy() for k, v in res[s].items()}
+    assert mm["first"].tolist() == list(range(n - s)), s
+    assert mm["match_count"].shape == (n - s,)
+    total = 0
+    for row, i in enumerate(mm["first"]):
+        want_m, want_q = _oracle_pair(fr, i, i + s)
+        c = int(mm["match_count"][row])
+        assert c == len(want_m), (s, i, c, len(want_m))
+        assert mm["matches"].dtype == np.int64 and np.array_equal(mm["matches"][row, :c], want_m), (s, i)
+        assert np.array_equal(mm["quality"][row, :c].view(np.uint32), want_q.view(np.uint32)), (s, i)
+        total += c
+    return total
+
+
+@pytest.mark.parametrize("chunk", [None, 7, 1])
+def test_streaming_sequence_all_spacings_vs_oracle(T, pipe, chunk):
+    from sslam_amd.harness import StreamingSequence
+    n = 27
+    toks, imgs = synth.token_sequence(n, 28), synth.image_sequence(n)
+    seq = StreamingSequence(pipe, SPACINGS)
+    res = seq.run(T.from_numpy(toks).cuda(), T.from_numpy(imgs).cuda(), chunk=chunk)
+    fr = {k: res["frames"][k].cpu().numpy() for k in ("descriptors", "scores", "intensity", "idx")}
+    # extraction itself: bit-exact vs the oracle chain (spot: three frames)
+    feat = ora.bn_tokens(toks[[0, 13, 26]])[0].reshape(3, 28, 28, 384)
+    _, _, oidx, _ = ora.select_keypoints(ora.selector_saliency(feat, synth.selector_state(0)), 500)
+    assert np.array_equal(fr["idx"][[0, 13, 26]], oidx)
+    totals = {s: _check_spacing(res, s, n, fr) for s in SPACINGS}
+    assert totals[1] > 0, "consecutive synthetic frames must have mutual matches"
+    # the reference's process_spacing visits rows 0, s, 2s, ... (and stops after max_pairs)
+    assert StreamingSequence.reference_pairs(n, 5) == [0, 5, 10, 15, 20]
+    assert StreamingSequence.reference_pairs(n, 5, max_pairs=1) == [0]
+    assert StreamingSequence.reference_pairs(n, 20) == [0]
+    assert seq.n_seen == n and seq._ring["descriptors"].shape[0] == 20
+
+
+def test_streaming_short_sequence_skips_long_spacings(T, pipe):
+    from sslam_amd.harness import StreamingSequence
+    toks = synth.token_sequence(6, 28)
+    res = StreamingSequence(pipe, SPACINGS).run(T.from_numpy(toks).cuda(), None, chunk=4)
+    assert set(res) == {"frames", 1, 5}
+    assert res[5]["match_count"].shape == (1,) and res[1]["match_count"].shape == (5,)
+
+
+def test_sequence_matcher_extract_from_png(T, tmp_path):
+    """The reference-shaped entry point end to end: a PNG on disk -> the dict of visualize_matches_sequence.py:97-104."""
+    from PIL import Image
+
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd import lib
+    from sslam_amd.harness import SequenceMatcher
+    from sslam_amd.vit import DinoV3ViT
+    T.manual_seed(11)
+    imgs = synth.image_sequence(2)
+    paths = []
+    for i in range(2):
+        paths.append(str(tmp_path / f"{i:04d}.png"))
+        Image.fromarray(imgs[i]).save(paths[-1])
+    bb = DinoBackbone(input_size=448, dino=DinoV3ViT().eval())
+    ssd, rsd = synth.selector_state(0), synth.refiner_state(0)
+    sm = SequenceMatcher(bb, ssd, rsd, device="cuda")
+    before = lib.launch_count()
+    f1, f2 = sm.extract(paths[0]), sm.extract(paths[1])
+    assert lib.launch_count() >= before + 2 * 90, "the HIP ViT and the HIP stages must have served extract()"
+    assert set(f1) == {"image", "saliency", "keypoints_pixel", "scores", "intensity", "descriptors"}
+    assert f1["saliency"].shape == (28, 28) and f1["keypoints_pixel"].shape == (500, 2) and f1["scores"].shape == (500,)
+    assert f1["intensity"].shape == (500,) and f1["descriptors"].shape == (500, 128)
+    assert all(f1[k].dtype == np.float32 for k in ("saliency", "keypoints_pixel", "scores", "intensity", "descriptors"))
+    assert f1["image"].size == (640, 480)
+    # values: the oracle chain on the tokens the backbone produced for the same file
+    for path, f, im in ((paths[0], f1, imgs[0]), (paths[1], f2, imgs[1])):
+        with T.no_grad():
+            tok = bb.forward_tokens(sm.pipe.preprocess(T.from_numpy(im[None]).cuda())).cpu().numpy()
+        feat = ora.bn_tokens(tok)[0].reshape(1, 28, 28, 384)
+        sal = ora.selector_saliency(feat, ssd)
+        kp, sc, idx, _ = ora.select_keypoints(sal, 500)
+        desc = ora.refine(ora.gather(feat, kp), rsd)
+        assert np.array_equal(f["saliency"].view(np.uint32), sal[0].view(np.uint32))
+        assert np.array_equal(f["keypoints_pixel"], ora.patch_to_pixel(kp[0]))
+        assert np.array_equal(f["scores"].view(np.uint32), sc[0].view(np.uint32))
+        assert np.array_equal(f["descriptors"].view(np.uint32), desc[0].view(np.uint32))
+        assert np.array_equal(f["intensity"], ora.intensity(im, 448, ora.patch_to_pixel(kp[0])))
+    m, q = sm.match_with_quality(f1["descriptors"], f2["descriptors"], f1["scores"], f2["scores"], intensity1=f1["intensity"],
+                                 intensity2=f2["intensity"], **CLI)
+    wm, wq = ora.match_with_quality(f1["descriptors"], f2["descriptors"], f1["scores"], f2["scores"], 0.3, 0.5, 0.7,
+                                    f1["intensity"], f2["intensity"], 0.15)
+    assert m.dtype == np.int64 and q.dtype == np.float32 and np.array_equal(m, wm) and np.array_equal(q, wq)
+
+
+def test_vit_precision_agreement(T, pipe):
+    """bf16 HIP ViT vs the fp32 definition on the same weights and frames: how many keypoints / matches agree.
+    (Random ViT weights give a flat, noise-like saliency field - the hardest case for a discontinuous selector.)"""
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd.vit import DinoV3ViT
+    T.manual_seed(5)
+    vit = DinoV3ViT().eval()
+    imgs = T.from_numpy(synth.image_sequence(6)).cuda()
+    outs = {}
+    for prec in ("bf16", "fp32"):
+        bb = DinoBackbone(input_size=448, dino=vit, vit_precision=prec).cuda()
+        with T.no_grad():
+            tok = bb.forward_tokens(pipe.preprocess(imgs)).float().contiguous()
+        outs[prec] = (tok, pipe.run(imgs, tok))
+    tb, tf = outs["bf16"][0], outs["fp32"][0]
+    rel = float((tb - tf).norm() / tf.norm())
+    ib, i32 = outs["bf16"][1]["idx"].cpu().numpy(), outs["fp32"][1]["idx"].cpu().numpy()
+    kp_agree = np.mean([len(set(a) & set(b)) / len(set(b)) for a, b in zip(ib, i32)])
+    mb, mf = outs["bf16"][1], outs["fp32"][1]
+    agree = tot = 0
+    for p in range(5):
+        cb, cf = int(mb["match_count"][p]), int(mf["match_count"][p])
+        sb = {(int(ib[p][a]), int(ib[p + 1][b])) for a, b in mb["matches"][p, :cb].cpu().numpy()}     # as grid cells
+        sf = {(int(i32[p][a]), int(i32[p + 1][b])) for a, b in mf["matches"][p, :cf].cpu().numpy()}
+        agree += len(sb & sf)
+        tot += max(len(sf), 1)
+    print(f"\nViT bf16 vs fp32: token rel err {rel:.2e}, keypoint-set agreement {kp_agree:.3f}, "
+          f"match agreement (cell pairs) {agree / tot:.3f}")
+    assert rel < 2.5e-2
+    assert kp_agree > 0.80, kp_agree
+
+
+def test_unsupported_dims_take_the_eager_path(T):
+    from models.descriptor_refiner import DescriptorRefiner
+    from models.keypoint_selector import KeypointSelector
+    from sslam_amd import lib
+    T.manual_seed(0)
+    sel = KeypointSelector(384, 64).cuda().eval()
+    ref = DescriptorRefiner(384, 256, 64).cuda().eval()
+    feat = T.randn(2, 28, 28, 384, device="cuda")
+    before = lib.launch_count()
+    with T.no_grad(), pytest.warns(UserWarning, match="eager torch path"):
+        sal = sel(feat)
+    with T.no_grad(), pytest.warns(UserWarning, match="eager torch path"):
+        d = ref(T.randn(2, 50, 384, device="cuda"))
+    assert lib.launch_count() == before, "unsupported shapes must not reach the HIP kernels"
+    want = T.sigmoid(sel.conv(feat.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    assert sal.shape == (2, 28, 28, 1) and T.allclose(sal, want, atol=1e-6)
+    assert d.shape == (2, 50, 64) and T.allclose(d.norm(dim=-1), T.ones(2, 50, device="cuda"), atol=1e-5)
+    # the keypoint selection on that saliency still runs on the HIP kernel (shape independent)
+    kp, sc = sel.select_keypoints(sal, 100)
+    assert kp.shape == (2, 100, 2) and lib.launch_count() == before + 1
+
+
+def test_pipeline_raises_when_k_cannot_be_served(T):
+    """input_size 224 (196 cells) with K = 500: torch.topk raises in the reference; the batched pipeline does too."""
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    p14 = SequencePipeline(ExtractorConfig(input_size=224, num_keypoints=500), synth.selector_state(0), synth.refiner_state(0),
+                           device="cuda")
+    toks = T.from_numpy(synth.token_sequence(2, 14)).cuda()
+    with pytest.raises(RuntimeError, match="out of range"):
+        p14.extract(toks)

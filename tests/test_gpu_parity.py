@@ -145,9 +145,25 @@ def test_select_keypoints_vs_oracle(T, hip, grid, K, frames):
 
 
 def test_select_keypoints_k_too_large_sets_status(T, hip):
+    """K beyond what torch.topk can deliver (the reference raises, keypoint_selector.py:160/176): status = 1 and every slot
+    is still written - the oracle's truncate / pad rule (:186-199, sslam_oracle.c select_one), bit for bit."""
     g = gold("select_cases")
-    _, _, _, _, st = _select(T, hip, g["Belse_r2_map"][None], 28 * 28 + 200)
-    assert st[0] == 1
+    K = 28 * 28 + 200
+    m = g["Belse_r2_map"][None]
+    kp, sc, idx, px, st = _select(T, hip, m, K)
+    okp, osc, oidx, ost = ora.select_keypoints(m, K, 2, 0.5)
+    assert st[0] == 1 and ost[0] == 1
+    assert np.array_equal(idx, oidx) and np.array_equal(kp, okp)
+    assert_bits(sc, osc, "padded scores")
+    assert_bits(px, okp * 16 + 8, "padded pixels")
+    # branch C on a 14 x 14 grid with the default K = 500 (input_size 224): constant map, nothing above the threshold
+    rng = np.random.Generator(np.random.PCG64(5))
+    flat = np.stack([np.full((14, 14), 0.05, np.float32), rng.random((14, 14)).astype(np.float32) * np.float32(0.09)])
+    kp, sc, idx, px, st = _select(T, hip, flat, 500)
+    okp, osc, oidx, ost = ora.select_keypoints(flat, 500, 2, 0.5)
+    assert np.array_equal(st, ost) and st.tolist() == [1, 1]
+    assert np.array_equal(idx, oidx) and np.array_equal(kp, okp)
+    assert_bits(sc, osc, "padded scores (branch C)")
 
 
 # ---------------------------------------------------------------------------------------------------- A6 / A7

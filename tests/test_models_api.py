@@ -182,3 +182,95 @@ def test_training_step_runs_through_the_drop_in_modules():
     before = ref.output_proj.weight.detach().clone()
     opt.step()
     assert not torch.equal(before, ref.output_proj.weight)
+
+
+# ------------------------------------------------------------------------------------------ device / shape guards
+class _FakeCuda:
+    """just enough of a tensor for lib.common_device: .is_cuda and .device"""
+
+    def __init__(self, index):
+        self.is_cuda, self.device = True, torch.device("cuda", index)
+
+
+def test_lib_rejects_cpu_and_mixed_device_arguments():
+    from sslam_amd import lib
+    a, b = _FakeCuda(0), _FakeCuda(1)
+    assert lib.common_device(a, None, _FakeCuda(0)) == torch.device("cuda", 0)
+    with pytest.raises(ValueError, match="different devices"):
+        lib.common_device(a, b)
+    with pytest.raises(ValueError, match="CUDA tensors only"):
+        lib.common_device(a, torch.zeros(3))
+    with pytest.raises(ValueError):
+        lib.common_device(None)
+    # a wrapper handed CPU tensors raises a clean Python error before anything reaches the C ABI
+    before = lib.launch_count()
+    with pytest.raises(ValueError):
+        lib.gather(torch.zeros(1, 4, 4, 384), torch.zeros(1, 3, 2))
+    with pytest.raises(ValueError):
+        lib.select_keypoints(torch.zeros(1, 4, 4), 3)
+    assert lib.launch_count() == before
+
+
+def test_backbone_vit_precision_flag_and_device_guard():
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd.vit import DinoV3ViT
+    with pytest.raises(ValueError, match="vit_precision"):
+        DinoBackbone(dino=TokenDino(), vit_precision="fp16")
+    torch.manual_seed(0)
+    vit = DinoV3ViT(depth=1)
+    bb = DinoBackbone(input_size=32, dino=vit, vit_precision="bf16")
+    x = torch.randn(1, 3, 32, 32)
+    assert bb._hip_vit(x) is None                      # CPU images: never the HIP ViT
+    # a CUDA image with a CPU-resident module must not hand host pointers to the kernels: _hip_vit says None and the
+    # eager path raises torch's own device error (checked with a stand-in that only carries .is_cuda / .device)
+    class _Img(_FakeCuda):
+        pass
+    assert bb._hip_vit(_Img(0)) is None
+    assert DinoBackbone(input_size=32, dino=vit, vit_precision="fp32")._hip_vit(_Img(0)) is None
+    with torch.no_grad():
+        f = bb(x)                                      # eager fp32 definition on CPU, both precisions agree there
+        f32 = DinoBackbone(input_size=32, dino=vit, vit_precision="fp32")(x)
+    assert f.shape == (1, 2, 2, 384) and torch.equal(f, f32)
+
+
+def test_unsupported_dims_fall_back_to_eager_on_cpu_too():
+    from models.descriptor_refiner import DescriptorRefiner
+    from models.keypoint_selector import KeypointSelector
+    from sslam_amd.pipeline import PackedRefiner, PackedSelector
+    assert PackedSelector.supported((256, 384, 3, 3)) and PackedSelector.supported((128, 384, 3, 3))
+    assert not PackedSelector.supported((64, 384, 3, 3)) and not PackedSelector.supported((256, 256, 3, 3))
+    assert PackedRefiner.supported(384, 384, 128, 2) and not PackedRefiner.supported(384, 256, 128, 2)
+    assert not PackedRefiner.supported(384, 384, 64, 2)
+    sel, ref = KeypointSelector(384, 64).eval(), DescriptorRefiner(384, 256, 64).eval()
+    with torch.no_grad():
+        assert sel(torch.randn(1, 6, 6, 384)).shape == (1, 6, 6, 1)
+        assert ref(torch.randn(1, 5, 384)).shape == (1, 5, 64)
+
+
+def test_streaming_scheduler_pair_bookkeeping():
+    """The reference's pair set (visualize_matches_sequence.py:298-300) and the ring arithmetic, without a GPU."""
+    from sslam_amd.harness import StreamingSequence
+    assert StreamingSequence.reference_pairs(613, 5)[:3] == [0, 5, 10]
+    assert StreamingSequence.reference_pairs(613, 5)[-1] == 605 and len(StreamingSequence.reference_pairs(613, 20)) == 30
+    assert StreamingSequence.reference_pairs(613, 20, max_pairs=1) == [0]
+    assert StreamingSequence.reference_pairs(3, 5) == []
+
+    class _Pipe:                                   # records what the scheduler asks for; frames are their own index
+        class cfg:
+            spacing = 1
+
+        def extract(self, tokens, images=None):
+            return {"descriptors": tokens.clone(), "scores": tokens.clone()}
+
+        def match(self, desc, scores, intensity=None, spacing=1):
+            n = desc.shape[0] - spacing
+            return {"match_count": torch.zeros(n, dtype=torch.int32), "pair": torch.stack([desc[:n], desc[spacing:]], 1)}
+
+    n = 31
+    frames = torch.arange(n, dtype=torch.float32)
+    for chunk in (None, 1, 4, 13, 40):
+        res = StreamingSequence(_Pipe(), (1, 5, 10, 15, 20)).run(frames, None, chunk=chunk)
+        for s in (1, 5, 10, 15, 20):
+            want = torch.stack([frames[:n - s], frames[s:]], 1)
+            assert torch.equal(res[s]["pair"], want), (chunk, s)
+            assert res[s]["first"].tolist() == list(range(n - s))

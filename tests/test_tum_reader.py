@@ -47,3 +47,26 @@ def test_tum_sequence_layout_and_quirks(tmp_path):
     assert len(seq2) == 4 and seq2.poses.shape[0] == 4
     with pytest.raises(AssertionError):
         TUMSequence(str(tmp_path / "nope"))
+
+
+def test_tum_sequence_equals_the_reference_loader(tmp_path):
+    """Pinned: tests/golden/tum_reader.npz holds what the reference's own TUMDataset (data/tum_dataset.py:27-95, 210-255,
+    run by tests/golden/make_golden_tum.py) loads from the directory synth.write_tum_sequence writes."""
+    import os
+
+    import synth
+    from sslam_amd.tum import TUMSequence, quat_to_matrix
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tum_reader.npz"))
+    name = "rgbd_dataset_freiburg1_desk"
+    created = synth.write_tum_sequence(str(tmp_path / name))
+    assert created != sorted(created), "the fixture directory is written out of order on purpose"
+    cases = {"full": (TUMSequence(str(tmp_path), name), 1),
+             "max4": (TUMSequence(str(tmp_path), name, max_frames=4), 2),
+             "direct": (TUMSequence(str(tmp_path / name), "not_a_subdir"), 1)}
+    for tag, (seq, spacing) in cases.items():
+        assert seq.rgb_files == bytes(g[f"{tag}_rgb"]).decode().split(","), tag
+        assert seq.depth_files == bytes(g[f"{tag}_depth"]).decode().split(","), tag
+        assert np.array_equal(np.asarray(seq.timestamps, np.float64), g[f"{tag}_timestamps"]), tag
+        assert np.array_equal(seq.poses, g[f"{tag}_poses"]), tag            # same arithmetic: bit-equal float64
+        assert seq.n_pairs(spacing) == int(g[f"{tag}_len"]), tag
+    assert np.array_equal(quat_to_matrix(0.3, -0.1, 0.7, 1.2, 1.0, 2.0, 3.0), g["quat_pose"])
