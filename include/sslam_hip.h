@@ -180,9 +180,12 @@ int sslam_match_finalize(const int32_t *nn12, const float *s12, const int32_t *n
  * embedding, [CLS] + 4 register tokens, 12 pre-LN blocks (6 heads x 64, q/v/proj bias, axial RoPE theta 100 on the
  * patch tokens, LayerScale, MLP 1536 GELU), final LayerNorm.  bf16 MFMA operands, fp32 accumulation / LayerNorm /
  * softmax / residual stream: tolerance-level parity with an fp32 evaluation (not bit-exact).
- * All pointers are DEVICE pointers; vectors fp32; matrices bf16, nn.Linear (n_out, k_in) re-ordered into MFMA
- * B-fragment order [n_out/32][k_in/16][2][32][8] (element (n, k) -> [n/32][k/16][(k%16)/8][n%32][k%8]).
- * wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), bqkv likewise with ZEROS for the k rows (no key bias);
+ * All pointers are DEVICE pointers; vectors fp32; matrices bf16, nn.Linear (n_out, k_in) re-ordered by
+ * sslam_vit_pack_linear_host into the order the GEMM kernel streams them: one 1 KB MFMA fragment per (192-column tile,
+ * k-step of 16, 32-column slice): element (n, k) -> [n/192][k/16][(n%192)/32][(k%16)/8][n%32][k%8].
+ * wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), bqkv likewise with ZEROS for the k rows (no key bias), the q rows of
+ * both multiplied by log2(e)/sqrt(64) (softmax runs in the exp2 domain); wo / bo and wdown / bdown multiplied row-wise by
+ * the block's LayerScale (ls1, ls2) - the caller folds these constants before packing (sslam_amd/vit_hip.py does);
  * patch_w = Conv2d weight reshaped (384, 768); prefix = [cls; reg0..3] (5, 384); rope_cos / rope_sin (G*G, 64) fp32.
  * images_chw (n, 3, size, size) fp32 (the output of sslam_preprocess_u8) -> tokens_out (n, 5 + (size/16)^2, 384). */
 typedef struct {
@@ -190,11 +193,11 @@ typedef struct {
     const void *wqkv;
     const float *bqkv;
     const void *wo;
-    const float *bo, *ls1, *ln2_g, *ln2_b;
+    const float *bo, *ln2_g, *ln2_b;
     const void *wup;
     const float *bup;
     const void *wdown;
-    const float *bdown, *ls2;
+    const float *bdown;
 } sslam_vit_layer_t;
 typedef struct {
     const void *patch_w;
@@ -202,6 +205,8 @@ typedef struct {
     sslam_vit_layer_t layer[12];
     const float *norm_g, *norm_b, *rope_cos, *rope_sin;
 } sslam_vit_weights_t;
+/* host helper: fp32 nn.Linear weight (n_out, k_in), n_out % 192 == 0, k_in % 384 == 0 -> the packed bf16 image above */
+int sslam_vit_pack_linear_host(const float *w, int n_out, int k_in, uint16_t *out);
 long long sslam_vit_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
                       void *workspace, long long workspace_bytes, float *tokens_out, void *stream);

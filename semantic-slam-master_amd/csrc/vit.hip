@@ -14,6 +14,9 @@
 // registers (no LDS round trip for P); K is rotated and V transposed once per layer by kv_prep_kernel.
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -28,240 +31,516 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// ------------------------------------------------------------------------------- A-resident GEMM (K in chunks of 384)
-// C (M x N) = A (M x K, bf16 row-major) . W^T, W pre-packed in MFMA-fragment order [N/32][K/16][2][32][8] bf16
-// (fragment element = lane: half h = lane>>5 holds k = 8h..8h+7 of row lane&31).
-// Work item = (128-row tile, column group of 128*S); persistent workgroups of 4 waves walk the items.  The item's
-// 128 x 384 A chunk lives in LDS (392-element rows); wave w owns the 32-column slices {s*4 + w} of the group, i.e.
-// 128 rows x 32 columns per slice = 4 MFMA tiles per B fragment (the reuse that keeps the L1 path under its 64 B/clk).
-// B fragments go global -> registers (1 KB coalesced per wave-instruction, 4-deep ring); the NEXT chunk's A rows are
-// prefetched into registers one 16-B piece per k-step, so the main loop has no barrier and chunk hand-over costs two.
-#ifndef SSLAM_ARES_MT
-#define SSLAM_ARES_MT 2
-#endif
-#ifndef SSLAM_ARES_OCC
-#define SSLAM_ARES_OCC 3
-#endif
-constexpr int ARES_OCC = SSLAM_ARES_OCC;   // workgroups per CU the register budget is sized for (MT == 2)
-constexpr int MT = SSLAM_ARES_MT;   // M tiles per wave: 2 -> 64-row workgroups, 50 KB LDS, 3 co-resident per CU (latencies of one
-                                    // overlap the MFMAs of the others); 4 -> 128 rows, 1 per CU (measured slower: nothing overlaps)
-constexpr int RM128 = 32 * MT, KC = 384, ALD2 = KC + 8, KSTEPS = KC / 16, A_PIECES = RM128 * (KC / 8) / 256;   // pieces / thread
-#ifndef SSLAM_BRING
-#define SSLAM_BRING 8
-#endif
-constexpr int BRING = SSLAM_BRING;   // B fragments in flight per wave (1 KB each): Little's law needs >= 32 KB per CU
+// ------------------------------------------------------------------- row-tile GEMM: A in registers, B through LDS
+// C (M x N) = A (M x K, K = 384 * KC) . W^T with W pre-packed by sslam_vit_pack_linear_host in the order the kernel
+// consumes it: [N/192][K/16][6][64 lanes][8] bf16 - one 1 KB MFMA fragment per (192-column tile, k-step, 32-column
+// slice), so a "group" of 4 k-steps is 24 KB of CONTIGUOUS global memory.
+//
+// Workgroup = 4 waves = 128 rows x (nt_per_part tiles of 192 columns); wave w owns rows 32w..32w+31 and keeps their A
+// fragments for the current 384-wide K chunk in REGISTERS (24 fragments = 96 VGPRs), so the matrix pipe needs ONE
+// ds_read_b128 per MFMA.  The weight stream goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: a linear copy, 6 KB per
+// wave and group, no registers, no address arithmetic) into a 2 x 24 KB ring: group g+1 is in flight while group g is
+// multiplied; one barrier per group.  Two workgroups per CU (2 x 66 KB LDS, 8 waves) so that one's prologue / epilogue
+// overlaps the other's MFMAs.
+//
+// Every global access of activations is a FULL 128-byte line per 8 lanes: rows are loaded / stored in row-major pieces
+// (lane = (row q of 8, 16-byte piece p of 8)) and transposed to / from the MFMA layouts through a 4.5 KB wave-private LDS
+// tile (144-byte rows: conflict-free fragment reads) - fragment-shaped global accesses (32 rows x 32 B per instruction)
+// cost 2-4x the time of the whole MFMA loop (measured: o_proj 37 us with them, 10 us of MFMA loop).
+// The product is evaluated TRANSPOSED (weights = MFMA A operand, activations = B operand): a lane owns ONE token and 4
+// consecutive output features per accumulator quad, so the epilogue stages 8- / 16-byte pieces.
+//
+// LayerNorm is folded in: the residual epilogues (o_proj, down_proj, patch embedding) emit per-row partial (sum, sum of
+// squares) of the NEW residual stream for their 192-column half, and the prologue of the consuming GEMM (QKV, up_proj)
+// normalises the fp32 rows while it converts them to bf16 fragments - no LayerNorm kernel, no bf16 copy of the stream.
+constexpr int RT_BM = 128, RT_NT = 192, RT_SL = RT_NT / 32, RT_GK = 4, RT_KS = 24, RT_NG = RT_KS / RT_GK;
+constexpr int RT_STEP_ELEMS = RT_SL * 512;                 // bf16 elements per k-step slab (6 fragments of 1 KB)
+constexpr int RT_GROUP_BYTES = RT_GK * RT_SL * 1024;        // 24 576
+constexpr int RT_PIECES = RT_GK * RT_SL / 4;                // 1 KB DMA pieces per wave and group (6)
+constexpr int RT_STG_ROW = 144, RT_STG_BYTES = 32 * RT_STG_ROW;            // wave-private transposition tile
+constexpr int RT_LDS_BYTES = 2 * RT_GROUP_BYTES + 4 * RT_STG_BYTES;         // 67 584 -> two workgroups per CU
 
-template <int S, class Epi>
-__global__ __launch_bounds__(256, MT <= 3 ? ARES_OCC : 1) void gemm_ares_kernel(const bf16 *__restrict__ A, const bf16 *__restrict__ Wp, int M, int N,
-                                                            int K, int n_items, int n_groups, Epi epi) {
-    __shared__ __attribute__((aligned(16))) bf16 As[RM128 * ALD2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int nchunk = K / KC;
-    const int kfr = K / 16;                                  // k-steps per full row of W
-    // A staging map: piece p of thread t = row (t>>4) + 16*(p % RB), 16-B column (t&15) + 16*(p / RB), RB = rows/16:
-    // 16 consecutive threads move 256 contiguous bytes of one row; no per-piece address registers are kept.
-    const int srow = tid >> 4, scol = (tid & 15) * 8;
-    u32x4 pre[A_PIECES];
-#define A_SRC(rt_, kc_, p_)                                                                                \
-    reinterpret_cast<const u32x4 *>(A + (long long)min((rt_) * RM128 + srow + 16 * ((p_) % RB), M - 1) * K + \
-                                    (kc_) * KC + scol + 128 * ((p_) / RB))
-#define A_DST(p_) reinterpret_cast<u32x4 *>(As + (srow + 16 * ((p_) % RB)) * ALD2 + scol + 128 * ((p_) / RB))
-    constexpr int RB = RM128 / 16;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
-    // contiguous, balanced item range per workgroup: consecutive items share their row tile, so for K = 384 the A tile is
-    // staged once per row tile and reused for all its column groups
-    const int per = n_items / gridDim.x, extra = n_items % gridDim.x, b = blockIdx.x;
-    const int item_lo = b * per + min(b, extra), item_hi = item_lo + per + (b < extra ? 1 : 0);
-    if (item_lo >= item_hi) return;
-    int item = item_lo;
+__device__ __forceinline__ void rt_dma_group(const bf16 *src, char *dst, int wave, int lane) {
 #pragma unroll
-    for (int p = 0; p < A_PIECES; p++) pre[p] = *A_SRC(item / n_groups, 0, p);
-#pragma unroll
-    for (int p = 0; p < A_PIECES; p++) *A_DST(p) = pre[p];
-    __syncthreads();
-
-    const bf16 *Ab = As + r * ALD2 + 8 * h;
-    for (; item < item_hi; item++) {
-        const int ng = item % n_groups, rt = item / n_groups;
-        f32x16 acc[S][MT];
-#pragma unroll
-        for (int s = 0; s < S; s++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[s][mt][e] = 0.0f;
-
-        for (int kc = 0; kc < nchunk; kc++) {
-            // what comes after this chunk (next K chunk of the item, or the first chunk of the next item)?
-            const bool last_kc = kc + 1 == nchunk;
-            const int nitem = last_kc ? item + 1 : item, nkc = last_kc ? 0 : kc + 1;
-            // the next (item, chunk) needs a different A chunk unless K is one chunk and the row tile stays the same
-            const int nrt = nitem / n_groups;
-            const bool have_next = nitem < item_hi && !(nchunk == 1 && nrt == rt);
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                const int slice = ng * (4 * S) + s * 4 + wave;                  // 32-column slice of N
-                const bf16x8 *bsrc = reinterpret_cast<const bf16x8 *>(Wp) + ((long long)slice * kfr + kc * KSTEPS) * 64 + lane;
-                bf16x8 bq[BRING];
-#pragma unroll
-                for (int i = 0; i < BRING; i++) bq[i] = bsrc[i * 64];
-                bf16x8 an[MT], ac[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) an[mt] = *reinterpret_cast<const bf16x8 *>(Ab + mt * 32 * ALD2);
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ks++) {
-                    // software pipeline, program order = issue order: A fragments of step ks+1 (LDS), the B fragment of
-                    // step ks+4 and one piece of the next chunk (global) are requested BEFORE the four MFMAs of step ks
-                    const bf16x8 bnow = bq[ks % BRING];
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) ac[mt] = an[mt];
-                    if (ks + 1 < KSTEPS) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; mt++)
-                            an[mt] = *reinterpret_cast<const bf16x8 *>(Ab + mt * 32 * ALD2 + (ks + 1) * 16);
-                    }
-                    if (ks + BRING < KSTEPS) bq[ks % BRING] = bsrc[(ks + BRING) * 64];
-                    if (s == 0 && have_next && ks < A_PIECES) pre[ks] = *A_SRC(nrt, nkc, ks);
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[s][mt] = mfma_bf16(ac[mt], bnow, acc[s][mt]);
-                    __builtin_amdgcn_sched_barrier(0);      // keep this order; do not hoist later LDS reads up here
-                }
-            }
-            if (have_next) {
-                __syncthreads();                   // every wave is done reading this chunk
-#pragma unroll
-                for (int p = 0; p < A_PIECES; p++) *A_DST(p) = pre[p];
-            }
-            if (last_kc) {
-                // epilogue of the item (registers only)
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    epi.slice(acc[s], rt * RM128, (ng * (4 * S) + s * 4 + wave) * 32, r, h, M);
-                }
-            }
-            if (have_next) __syncthreads();
-        }
+    for (int i = 0; i < RT_PIECES; i++) {
+        const int piece = wave * RT_PIECES + i;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 512 + lane * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
     }
-#undef A_SRC
-#undef A_DST
 }
 
-// x[row, col] += ls[col] * (acc + bias[col])          (o_proj / down_proj: LayerScale + residual, fp32 stream)
-struct EpiResidual {
-    const float *bias, *ls;
-    float *x;
-    __device__ __forceinline__ void slice(f32x16 (&acc)[MT], int row0, int col0, int r, int h, int M) const {
-        const int col = col0 + r;
-        const float b = bias[col], l = ls[col];
-        int loff = 4 * h * VD + col;                 // lane part of the address; kept opaque so that the 32 per-element
-        asm volatile("" : "+v"(loff));               // addresses are formed at use instead of being hoisted into 64 VGPRs
-        float *base = x + (long long)row0 * VD + loff;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (bf16)lo;
+    v[1] = (bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// Activation loads that hipcc must not schedule or wait for: beside LDS-DMA traffic it serialises every ordinary global
+// load (load, s_waitcnt vmcnt(0), use - one memory round trip EACH; measured 37k cycles for the 52 loads of the LayerNorm
+// prologue).  These asm loads are invisible to its counters; rt_wait<N>() is the hand-placed s_waitcnt vmcnt(N) that also
+// names the registers it guards (so that no use is moved above it).  Vector-memory operations retire in issue order.
+__device__ __forceinline__ void rt_gload(f32x4 &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void rt_gload(bf16x8 &dst, const bf16 *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N, class T>
+__device__ __forceinline__ void rt_wait4(T &a, T &b, T &c, T &d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+// ---- prologues: fill the wave's 24 A fragments (rows row0 .. row0+31, k chunk kc) -------------------------------------
+// fragment ks of lane (r = lane & 31, h = lane >> 5) = the 8 bf16 at [row r][16 ks + 8 h ..]
+
+struct ProBf16 {          // A is a bf16 row-major matrix with row length K
+    const bf16 *A;
+    int K;
+    static constexpr int VEC = 0;
+    __device__ __forceinline__ void fill(float *vec, int tid) const {}
+    __device__ __forceinline__ void load(bf16x8 (&a)[RT_KS], int row0, int kc, char *stg, const float *vec, int lane, int M) const {
+        const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
+        const bf16 *ar[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int i = 0; i < 4; i++) ar[i] = A + (long long)min(row0 + 8 * i + q, M - 1) * K + kc * 384 + 8 * p;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int o = mt * 32 + (e & 3) + 8 * (e >> 2);
-                if (row0 + o + 4 * h < M) {
-                    float *p = base + o * VD;
-                    *p = *p + l * (acc[mt][e] + b);
-                }
-            }
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) rt_gload(a[4 * c + i], ar[i] + 64 * c);
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            if (c == 0) rt_wait4<20>(a[0], a[1], a[2], a[3]);          // batch c has landed: 4 (5 - c) younger loads may fly on
+            if (c == 1) rt_wait4<16>(a[4], a[5], a[6], a[7]);
+            if (c == 2) rt_wait4<12>(a[8], a[9], a[10], a[11]);
+            if (c == 3) rt_wait4<8>(a[12], a[13], a[14], a[15]);
+            if (c == 4) rt_wait4<4>(a[16], a[17], a[18], a[19]);
+            if (c == 5) rt_wait4<0>(a[20], a[21], a[22], a[23]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<bf16x8 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p) = a[4 * c + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[4 * c + j] = *reinterpret_cast<const bf16x8 *>(stg + r * RT_STG_ROW + 32 * j + 16 * h);
+        }
     }
 };
 
-// exact-erf GELU (torch's default) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
-// rounding of the result): 15 VALU operations, two of them transcendental, instead of libm's ~45 - the up_proj epilogue
-// is VALU-bound (64 x 1536 activations per 64-row tile against 48 MFMAs per wave and item)
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float ax = fabsf(v) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-    float p = 1.061405429f;
-    p = __builtin_fmaf(p, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    p = p * t;
-    const float e = __builtin_amdgcn_exp2f(ax * ax * -LOG2E);
-    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
-    return v * __builtin_fmaf(0.5f, __builtin_copysignf(erf_abs, v), 0.5f);
+struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, statistics from the producing epilogue
+    const float *x;
+    const float4 *stats;                  // per row: (sum, sumsq) of columns 0..191, (sum, sumsq) of columns 192..383
+    const float *gamma, *beta;
+    float eps;
+    static constexpr int VEC = 2 * VD;    // gamma, beta cached in LDS: no global-load latency between the row batches
+    __device__ __forceinline__ void fill(float *vec, int tid) const {
+        for (int i = tid; i < VD; i += 256) {
+            vec[i] = gamma[i];
+            vec[VD + i] = beta[i];
+        }
+    }
+    __device__ __forceinline__ void load(bf16x8 (&a)[RT_KS], int row0, int kc, char *stg, const float *vec, int lane, int M) const {
+        const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
+        float mean[4], rstd[4];
+        const float *xr[4];
+        f32x4 st4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) rt_gload(st4[i], reinterpret_cast<const float *>(stats + min(row0 + 8 * i + q, M - 1)));
+        rt_wait4<0>(st4[0], st4[1], st4[2], st4[3]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = min(row0 + 8 * i + q, M - 1);
+            const f32x4 st = st4[i];
+            mean[i] = (st.x + st.z) * (1.0f / VD);
+            const float var = fmaxf((st.y + st.w) * (1.0f / VD) - mean[i] * mean[i], 0.0f);
+            rstd[i] = rsqrtf(var + eps);
+            xr[i] = x + (long long)row * VD + 4 * p;
+        }
+        // six batches of 64 features; batch c + 1 is in flight while batch c is normalised (two register sets, named)
+        f32x4 xa[2][4], xb[2][4];
+#define LN_LOAD(dst, c_)                                                                                             \
+    _Pragma("unroll") for (int hf = 0; hf < 2; hf++) _Pragma("unroll") for (int i = 0; i < 4; i++)                     \
+        rt_gload(dst[hf][i], xr[i] + 64 * (c_) + 32 * hf);
+#define LN_WAIT(src, n_)                                                                                             \
+    rt_wait4<n_>(src[0][0], src[0][1], src[0][2], src[0][3]);                                                         \
+    rt_wait4<n_>(src[1][0], src[1][1], src[1][2], src[1][3]);
+#define LN_EMIT(src, c_)                                                                                             \
+    _Pragma("unroll") for (int hf = 0; hf < 2; hf++) {                                                                \
+        const float4 gm = *reinterpret_cast<const float4 *>(vec + 64 * (c_) + 32 * hf + 4 * p);                       \
+        const float4 bt = *reinterpret_cast<const float4 *>(vec + VD + 64 * (c_) + 32 * hf + 4 * p);                  \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                               \
+            const f32x4 v = src[hf][i];                                                                               \
+            uint2 o;                                                                                                  \
+            o.x = pack_bf16x2((v.x - mean[i]) * rstd[i] * gm.x + bt.x, (v.y - mean[i]) * rstd[i] * gm.y + bt.y);      \
+            o.y = pack_bf16x2((v.z - mean[i]) * rstd[i] * gm.z + bt.z, (v.w - mean[i]) * rstd[i] * gm.w + bt.w);      \
+            *reinterpret_cast<uint2 *>(stg + (8 * i + q) * RT_STG_ROW + 64 * hf + 8 * p) = o;                         \
+        }                                                                                                             \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                     \
+        a[4 * (c_) + j] = *reinterpret_cast<const bf16x8 *>(stg + r * RT_STG_ROW + 32 * j + 16 * h);
+        LN_LOAD(xa, 0)
+        LN_LOAD(xb, 1)
+        LN_WAIT(xa, 8)                 // the 8 loads of the younger batch may still be in flight
+        LN_EMIT(xa, 0)
+        LN_LOAD(xa, 2)
+        LN_WAIT(xb, 8)
+        LN_EMIT(xb, 1)
+        LN_LOAD(xb, 3)
+        LN_WAIT(xa, 8)
+        LN_EMIT(xa, 2)
+        LN_LOAD(xa, 4)
+        LN_WAIT(xb, 8)
+        LN_EMIT(xb, 3)
+        LN_LOAD(xb, 5)
+        LN_WAIT(xa, 8)
+        LN_EMIT(xa, 4)
+        LN_WAIT(xb, 0)
+        LN_EMIT(xb, 5)
+#undef LN_WAIT
+#undef LN_LOAD
+#undef LN_EMIT
+    }
+};
+
+// The bias of this workgroup's tiles is cached in LDS (the accumulators start from it); LayerScale and the 1/sqrt(d) of q are
+// folded into the packed weights and biases on the host (sslam_amd/vit_hip.py), so the epilogues only touch activations.
+__device__ __forceinline__ void rt_fill_vec(float *dst, const float *src, int nt0, int nt_per_part, int tid) {
+    for (int i = tid; i < RT_NT * nt_per_part; i += 256) dst[i] = src[RT_NT * nt0 + i];
 }
 
-// out[row, col] = gelu(acc + bias[col]) as bf16       (up_proj; exact erf GELU = torch's default)
+#ifdef SSLAM_RT_PROBE
+// diagnostic build only (tools/rt_probe.py): shader-clock stamps of wave 0 per workgroup; never in the product build
+__device__ unsigned long long g_rt_probe[8 * 2048];
+#define RT_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define RT_ACC(dst, t1, t0) dst += (t1) - (t0)
+#else
+#define RT_STAMP(var)
+#define RT_ACC(dst, t1, t0)
+#endif
+
+template <int KC, int NTP, class Pro, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__restrict__ Wp, int M, int parts, Epi epi, int dbg) {
+    constexpr int nt_per_part = NTP;         // 192-column tiles per workgroup (compile time: with 1 the A fragments die before the epilogue)
+    extern __shared__ __attribute__((aligned(16))) char rt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blocks b and b + 8 share an XCD (round-robin dispatch): give them the same row tile, so that the second part's A rows
+    // come from that XCD's L2 (a speed choice only)
+    const int b16 = blockIdx.x / (8 * parts), bl = blockIdx.x % (8 * parts);
+    const int tile = min(b16 * 8 + (bl & 7), (M + RT_BM - 1) / RT_BM - 1), part = bl >> 3;
+    const bool dup = b16 * 8 + (bl & 7) >= (M + RT_BM - 1) / RT_BM;      // padding block of the last group of 8 tiles
+    const int nt0 = part * nt_per_part;
+    constexpr long long NT_ELEMS = (long long)KC * RT_KS * RT_STEP_ELEMS;       // packed elements per 192-column tile
+    if (dup) return;
+    const int row0 = tile * RT_BM + wave * 32;
+    char *stg = rt_smem + 2 * RT_GROUP_BYTES + wave * RT_STG_BYTES;
+    float *vec_pro = reinterpret_cast<float *>(rt_smem + 2 * RT_GROUP_BYTES + 4 * RT_STG_BYTES), *vec_epi = vec_pro + Pro::VEC;
+
+    // the weight stream is one linear walk: (n-tile, k chunk, k group) in loop order = memory order
+    const bf16 *wnext = Wp + (long long)nt0 * NT_ELEMS;
+    const int n_groups = nt_per_part * KC * RT_NG;
+    int issued = 1, buf = 0;
+    rt_dma_group(wnext, rt_smem, wave, lane);
+    wnext += RT_GK * RT_STEP_ELEMS;
+    pro.fill(vec_pro, tid);                      // small per-feature vectors (LayerNorm affine, bias) -> LDS
+    rt_fill_vec(vec_epi, epi.bias, nt0, nt_per_part, tid);
+    epi.fill_extra(vec_epi + RT_NT * nt_per_part, tid);
+    __syncthreads();
+
+#ifdef SSLAM_RT_PROBE
+    unsigned long long p_pro = 0, p_wait = 0, p_mma = 0, p_epi = 0;
+#endif
+    RT_STAMP(t_begin);
+    bf16x8 a[RT_KS];
+    if (KC == 1) {            // one K chunk: the fragments are loaded once, before any accumulator is live
+        RT_STAMP(t_p0);
+        pro.load(a, row0, 0, stg, vec_pro, lane, M);
+        RT_STAMP(t_p1);
+        RT_ACC(p_pro, t_p1, t_p0);
+    }
+#pragma unroll 1
+    for (int nt = 0; nt < nt_per_part; nt++) {
+        f32x16 acc[RT_SL];            // starts from the bias: feature 32 s + 8 g + 4 h + i of this tile sits in acc[s][4 g + i]
+#pragma unroll
+        for (int s = 0; s < RT_SL; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 b = *reinterpret_cast<const float4 *>(vec_epi + RT_NT * nt + 32 * s + 8 * g + 4 * (lane >> 5));
+                acc[s][4 * g + 0] = b.x;
+                acc[s][4 * g + 1] = b.y;
+                acc[s][4 * g + 2] = b.z;
+                acc[s][4 * g + 3] = b.w;
+            }
+        for (int kc = 0; kc < KC; kc++) {
+            if (KC > 1) {
+                RT_STAMP(t_p0);
+                pro.load(a, row0, kc, stg, vec_pro, lane, M);
+                RT_STAMP(t_p1);
+                RT_ACC(p_pro, t_p1, t_p0);
+            }
+#pragma unroll
+            for (int kg = 0; kg < RT_NG; kg++) {
+                RT_STAMP(t_w0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current group have landed
+                __syncthreads();                                   // ... everyone's; and everyone left the other buffer
+                RT_STAMP(t_w1);
+                RT_ACC(p_wait, t_w1, t_w0);
+                if (issued < n_groups) {
+                    rt_dma_group(wnext, rt_smem + (buf ^ 1) * RT_GROUP_BYTES, wave, lane);
+                    wnext += RT_GK * RT_STEP_ELEMS;
+                    issued++;
+                }
+                const char *bb = rt_smem + buf * RT_GROUP_BYTES + lane * 16;
+#pragma unroll
+                for (int kk = 0; kk < RT_GK; kk++)
+#pragma unroll
+                    for (int s = 0; s < RT_SL; s++) {
+                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(bb + (kk * RT_SL + s) * 1024);
+                        acc[s] = mfma_bf16(w, a[kg * RT_GK + kk], acc[s]);
+                    }
+                buf ^= 1;
+                RT_STAMP(t_w2);
+                RT_ACC(p_mma, t_w2, t_w1);
+            }
+        }
+        RT_STAMP(t_e0);
+        if (dbg & 2) {
+#pragma unroll
+            for (int s = 0; s < RT_SL; s++) asm volatile("" ::"v"(acc[s]));
+        } else
+            epi.tile(acc, row0, nt0 + nt, stg, vec_epi + RT_NT * nt_per_part, lane, M);
+        RT_STAMP(t_e1);
+        RT_ACC(p_epi, t_e1, t_e0);
+    }
+#ifdef SSLAM_RT_PROBE
+    if (tid == 0 && blockIdx.x < 2048) {
+        unsigned long long *o = g_rt_probe + 8 * blockIdx.x;
+        o[0] = __builtin_readcyclecounter() - t_begin;
+        o[1] = p_pro; o[2] = p_wait; o[3] = p_mma; o[4] = p_epi;
+    }
+#endif
+}
+
+// ---- epilogues -----------------------------------------------------------------------------------------------------
+// They see the transposed tile: lane (r, h) holds token row0 + r and, for slice s / quad g, the 4 consecutive output
+// features 192 nt + 32 s + 8 g + 4 h + {0..3} in acc[s][4g .. 4g+3].  Pieces are staged in the wave's LDS tile and leave
+// in row-major order: lane (q = lane >> 3, p = lane & 7) handles rows row0 + 8 i + q, i = 0..3, 16-byte piece p.
+
+// x[row, f] += acc on the fp32 residual stream (o_proj / down_proj; bias and LayerScale are already inside acc), plus the
+// LayerNorm partial sums of the new rows over this 192-column half (N = 384: nt is 0 or 1).  The 24 row pieces of x are
+// requested up front (the A fragments are dead by now: one memory latency for the whole tile instead of one per slice).
+struct EpiResidual {
+    const float *bias;                    // LayerScale-folded
+    float *x;
+    float2 *stats;
+    int extra_floats() const { return 0; }
+    __device__ __forceinline__ void fill_extra(float *, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+        const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
+        float *px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = x + (long long)min(row0 + 8 * i + q, M - 1) * VD + RT_NT * nt + 4 * p;
+        f32x4 xv[RT_SL][4];
+#pragma unroll
+        for (int s = 0; s < RT_SL; s++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) rt_gload(xv[s][i], px[i] + 32 * s);
+        float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < RT_SL; s++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4 *>(stg + r * RT_STG_ROW + 32 * g + 16 * h) =
+                    make_float4(acc[s][4 * g + 0], acc[s][4 * g + 1], acc[s][4 * g + 2], acc[s][4 * g + 3]);
+            // slice s of x has landed once at most 4 (5 - s) younger loads are outstanding (stores issued since only lower
+            // the count that is actually needed, never raise it: the wait is conservative)
+            if (s == 0) rt_wait4<20>(xv[0][0], xv[0][1], xv[0][2], xv[0][3]);
+            if (s == 1) rt_wait4<16>(xv[1][0], xv[1][1], xv[1][2], xv[1][3]);
+            if (s == 2) rt_wait4<12>(xv[2][0], xv[2][1], xv[2][2], xv[2][3]);
+            if (s == 3) rt_wait4<8>(xv[3][0], xv[3][1], xv[3][2], xv[3][3]);
+            if (s == 4) rt_wait4<4>(xv[4][0], xv[4][1], xv[4][2], xv[4][3]);
+            if (s == 5) rt_wait4<0>(xv[5][0], xv[5][1], xv[5][2], xv[5][3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 d = *reinterpret_cast<const float4 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p);
+                f32x4 v = xv[s][i];
+                v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+                if (row0 + 8 * i + q < M) *reinterpret_cast<f32x4 *>(px[i] + 32 * s) = v;
+                sum[i] += (v.x + v.y) + (v.z + v.w);
+                sq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                sum[i] += __shfl_xor(sum[i], o);
+                sq[i] += __shfl_xor(sq[i], o);
+            }
+            const int row = row0 + 8 * i + q;
+            if (p == 0 && row < M) stats[2 * (long long)row + nt] = make_float2(sum[i], sq[i]);
+        }
+    }
+};
+
+// GELU(v) = v * Phi(v) (torch's default, the erf form) with Phi(v) - 1/2 = y * P(y^2), y = clamp(v, -4, 4), P the degree-6
+// minimax polynomial (fitted by linear programming with Phi(4) pinned to 1, so the tails are exactly v and 0):
+// |error| <= 1.9e-4 in fp32 - below the bf16 rounding of the result (and below the tanh form's 4.7e-4).  10 plain
+// multiply-adds per value, no transcendental, all packable two-at-a-time (v_pk_fma_f32): the up_proj epilogue is
+// VALU-bound (96 activations per lane and tile against 144 MFMAs), the erf / exp / rcp form took 14 instructions per value.
+__device__ __forceinline__ float gelu_poly(float v) {
+    const float y = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+    const float t = y * y;
+    float p = 2.258823990e-08f;
+    p = __builtin_fmaf(p, t, -1.588827486e-06f);
+    p = __builtin_fmaf(p, t, 4.776385402e-05f);
+    p = __builtin_fmaf(p, t, -8.121865301e-04f);
+    p = __builtin_fmaf(p, t, 8.763681258e-03f);
+    p = __builtin_fmaf(p, t, -6.455437055e-02f);
+    p = __builtin_fmaf(p, t, 3.978702073e-01f);
+    return v * __builtin_fmaf(y, p, 0.5f);
+}
+
+// rows of 64 bf16 (two slices = 128 B per token) leave the staging tile as full lines: dst(i) = address of the 128-byte
+// row segment of token row0 + 8 i + q
+template <class RowPtr>
+__device__ __forceinline__ void rt_store_pair(const char *stg, int row0, int lane, int M, RowPtr dst) {
+    const int q = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p);
+        if (row0 + 8 * i + q < M) *reinterpret_cast<u32x4 *>(dst(i) + 8 * p) = v;
+    }
+}
+
+// out[row, f] = gelu(acc) as bf16       (up_proj; acc holds the bias already)
 struct EpiGelu {
     const float *bias;
     bf16 *out;
     int ldo;
-    __device__ __forceinline__ void slice(f32x16 (&acc)[MT], int row0, int col0, int r, int h, int M) const {
-        const int col = col0 + r;
-        const float b = bias[col];
-        int loff = 4 * h * ldo + col;
-        asm volatile("" : "+v"(loff));
-        bf16 *base = out + (long long)row0 * ldo + loff;
+    int extra_floats() const { return 0; }
+    __device__ __forceinline__ void fill_extra(float *, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+        const int q = lane >> 3, r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int pp = 0; pp < 3; pp++) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int o = mt * 32 + (e & 3) + 8 * (e >> 2);
-                if (row0 + o + 4 * h < M) {
-                    const float v = acc[mt][e] + b;
-                    base[(long long)o * ldo] = (bf16)gelu_erf(v);
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int s = 2 * pp + s2;
+                    uint2 o;
+                    o.x = pack_bf16x2(gelu_poly(acc[s][4 * g + 0]), gelu_poly(acc[s][4 * g + 1]));
+                    o.y = pack_bf16x2(gelu_poly(acc[s][4 * g + 2]), gelu_poly(acc[s][4 * g + 3]));
+                    *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 64 * s2 + 16 * g + 8 * h) = o;
                 }
-            }
+            rt_store_pair(stg, row0, lane, M, [&](int i) { return out + (long long)(row0 + 8 * i + q) * ldo + RT_NT * nt + 64 * pp; });
+        }
     }
 };
 
-// patch embedding: row = frame*cells + patch -> x[frame*T + 5 + patch, col] = acc + bias[col]
+// patch embedding: row = frame*cells + patch -> x[frame*T + 5 + patch, f] = acc; also the LayerNorm partial sums
 struct EpiPatch {
     const float *bias;
     float *x;
+    float2 *stats;
     int cells, T;
-    __device__ __forceinline__ void slice(f32x16 (&acc)[MT], int row0, int col0, int r, int h, int M) const {
-        const int col = col0 + r;
-        const float b = bias[col];
-        const int f0 = row0 / cells, p0 = row0 - f0 * cells;
-        int loff = 4 * h * VD + col;
-        asm volatile("" : "+v"(loff));
-        float *base = x + ((long long)f0 * T + VPREFIX + p0) * VD + loff;
-        const int wrap = cells - p0 - 4 * h;           // rows at in-tile offset >= wrap belong to the next frame(s)
+    int extra_floats() const { return 0; }
+    __device__ __forceinline__ void fill_extra(float *, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+        const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
+        float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        long long orow[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int i = 0; i < 4; i++) {
+            const int row = min(row0 + 8 * i + q, M - 1), f = row / cells;
+            orow[i] = (long long)f * T + VPREFIX + (row - f * cells);
+        }
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int o = mt * 32 + (e & 3) + 8 * (e >> 2);
-                if (row0 + o + 4 * h < M) {
-                    int skip = 0;                      // each frame boundary crossed skips that frame's 5 prefix rows
-                    if (o >= wrap) skip = VPREFIX;
-                    if (o >= wrap + cells) skip = 2 * VPREFIX;
-                    base[(long long)(o + skip) * VD] = acc[mt][e] + b;
-                }
+        for (int s = 0; s < RT_SL; s++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4 *>(stg + r * RT_STG_ROW + 32 * g + 16 * h) =
+                    make_float4(acc[s][4 * g + 0], acc[s][4 * g + 1], acc[s][4 * g + 2], acc[s][4 * g + 3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 v = *reinterpret_cast<const float4 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p);
+                if (row0 + 8 * i + q < M) *reinterpret_cast<float4 *>(x + orow[i] * VD + RT_NT * nt + 32 * s + 4 * p) = v;
+                sum[i] += (v.x + v.y) + (v.z + v.w);
+                sq[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                sum[i] += __shfl_xor(sum[i], o);
+                sq[i] += __shfl_xor(sq[i], o);
+            }
+            if (p == 0 && row0 + 8 * i + q < M) stats[2 * orow[i] + nt] = make_float2(sum[i], sq[i]);
+        }
     }
 };
 
-// QKV: + bias, RoPE on the patch tokens of q and k (pairs (d, d+32) are the two N tiles of this wave), q *= 1/8,
-// scatter to (B, H, T, 64) bf16.  The wave's 64 columns are exactly one head of one of q / k / v.
+// QKV: RoPE on the patch tokens of q and k, then scatter to (B, H, T, 64) bf16 (bias inside acc; the q rows of the weight /
+// bias carry log2(e)/sqrt(64), folded on the host).  A 192-column tile is three heads of one of q / k / v (tiles 0-1: q,
+// 2-3: k, 4-5: v), a slice pair is one head (128 B per token).  RoPE partners (d, d + 32) are the same accumulator slot of
+// the two slices of a pair, on the same lane.  The (G*G, 64) cos / sin tables are AXIAL (DINOv3: d % 32 < 16 depends on the
+// patch row only, the rest on the patch column only, tiled twice), so 4 x G x 16 floats describe them: cached in LDS
+// (7 KB at G = 28) - per-token global loads of cos / sin either stall every quad or, prefetched, spill the A fragments.
 struct EpiQKV {
-    const float *bias, *cosb, *sinb;
+    const float *bias;
+    const float *cosb, *sinb;
     bf16 *q, *k, *v;
-    int T;
-    // slice form: bias (+ 1/8 for q), scatter to (B, H, T, 64); RoPE is applied by the attention kernel on load
-    __device__ __forceinline__ void slice(f32x16 (&acc)[MT], int row0, int col0, int r, int h, int M) const {
-        const int which = col0 / VD, head = (col0 % VD) / VHD, d = (col0 % VHD) + r;
+    int T, G;
+    int extra_floats() const { return 4 * 16 * G; }
+    __device__ __forceinline__ void fill_extra(float *rope, int tid) const {
+        // [cos_y | sin_y | cos_x | sin_x], each (G, 16): row py of the y tables from token (py, 0), row px of the x tables
+        // from token (0, px)
+        for (int i = tid; i < 16 * G; i += 256) {
+            const int p = i >> 4, dd = i & 15;
+            rope[i] = cosb[(long long)p * G * VHD + dd];
+            rope[16 * G + i] = sinb[(long long)p * G * VHD + dd];
+            rope[32 * G + i] = cosb[(long long)p * VHD + 16 + dd];
+            rope[48 * G + i] = sinb[(long long)p * VHD + 16 + dd];
+        }
+    }
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *rope, int lane, int M) const {
+        const int q8 = lane >> 3, r = lane & 31, h = lane >> 5;
+        const int which = nt >> 1;
         bf16 *dst = which == 0 ? q : (which == 1 ? k : v);
-        const float b = bias[col0 + r], sc = which == 0 ? 0.125f * LOG2E : 1.0f;   // q: 1/sqrt(64) and the exp2 domain
-        const int f0 = row0 / T, t0 = row0 - f0 * T;      // one division per tile: a tile spans <= 2 frames (T > 128)
-        int loff = 4 * h * VHD + d;
-        asm volatile("" : "+v"(loff));
-        bf16 *base = dst + (((long long)f0 * VH + head) * T + t0) * VHD + loff;
-        const long long fstep = (long long)(VH - 1) * T * VHD;   // extra offset once the row wraps into frame f0 + 1
-        const int wrap = T - t0 - 4 * h;                          // first in-tile row offset o that belongs to frame f0 + 1
+        // rotation coefficients of this lane's token: v tiles, [CLS] and register tokens use the identity (cos 1, sin 0)
+        const int row_r = min(row0 + r, M - 1), t = row_r % T;
+        const int tp = max(t - VPREFIX, 0), py = tp / G, px = tp - py * G;
+        const float rot = (which < 2 && t >= VPREFIX) ? 1.0f : 0.0f, keep = 1.0f - rot;
+        long long orow[4];                 // (frame * 6 * T + t) * 64 of the four rows this lane stores
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int i = 0; i < 4; i++) {
+            const int row = min(row0 + 8 * i + q8, M - 1), f = row / T;
+            orow[i] = ((long long)f * VH * T + (row - f * T)) * VHD;
+        }
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int o = mt * 32 + (e & 3) + 8 * (e >> 2);
-                if (row0 + o + 4 * h < M) base[(long long)o * VHD + (o >= wrap ? fstep : 0)] = (bf16)((acc[mt][e] + b) * sc);
+        for (int pp = 0; pp < 3; pp++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                // the accumulators are only READ (rotating them in place made hipcc keep two copies and spill the A fragments)
+                const float *tc = rope + (g < 2 ? 0 : 32 * G) + (g < 2 ? py : px) * 16 + 8 * (g & 1) + 4 * h;
+                const float4 cs = *reinterpret_cast<const float4 *>(tc), sn = *reinterpret_cast<const float4 *>(tc + 16 * G);
+                const float cv[4] = {cs.x * rot + keep, cs.y * rot + keep, cs.z * rot + keep, cs.w * rot + keep};
+                const float sv[4] = {sn.x * rot, sn.y * rot, sn.z * rot, sn.w * rot};
+                float o0[4], o1[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float x0 = acc[2 * pp][4 * g + i], x1 = acc[2 * pp + 1][4 * g + i];
+                    o0[i] = x0 * cv[i] - x1 * sv[i];
+                    o1[i] = x1 * cv[i] + x0 * sv[i];
+                }
+                *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 16 * g + 8 * h) = make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3]));
+                *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 64 + 16 * g + 8 * h) = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
             }
+            const int head = 3 * (nt & 1) + pp;
+            rt_store_pair(stg, row0, lane, M, [&](int i) { return dst + orow[i] + (long long)head * T * VHD; });
+        }
     }
 };
 
@@ -323,135 +602,103 @@ __global__ __launch_bounds__(256) void im2patch_kernel(const float *__restrict__
     *reinterpret_cast<bf16x8 *>(out + patch * 768 + run * 8) = o;
 }
 
-__global__ __launch_bounds__(256) void prefix_rows_kernel(const float *__restrict__ prefix, int T, long long items, float *__restrict__ x) {
-    const long long it = (long long)blockIdx.x * 256 + threadIdx.x;   // items = B * 5 * 384
-    if (it >= items) return;
-    const int c = (int)(it % VD), i = (int)((it / VD) % VPREFIX);
-    const long long f = it / (VD * VPREFIX);
-    x[(f * T + i) * VD + c] = prefix[i * VD + c];
+// [CLS] + register rows of every frame, and their LayerNorm sums (both halves' worth in the first slot): one wave per row
+__global__ __launch_bounds__(64) void prefix_rows_kernel(const float *__restrict__ prefix, int T, float *__restrict__ x,
+                                                         float2 *__restrict__ stats) {
+    const int lane = threadIdx.x, i = blockIdx.x % VPREFIX;
+    const long long row = (long long)(blockIdx.x / VPREFIX) * T + i;
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float2 v = *reinterpret_cast<const float2 *>(prefix + i * VD + 128 * j + 2 * lane);
+        *reinterpret_cast<float2 *>(x + row * VD + 128 * j + 2 * lane) = v;
+        s += v.x + v.y;
+        s2 += v.x * v.x + v.y * v.y;
+    }
+    s = bfly64(s);
+    s2 = bfly64(s2);
+    if (lane == 0) {
+        stats[2 * row] = make_float2(s, s2);
+        stats[2 * row + 1] = make_float2(0.f, 0.f);
+    }
 }
 
 // --------------------------------------------------------------------------------------------- attention
-constexpr int AQ = 128, AKT = 64, KLD = 72, VLD = 76;
-
-// RoPE (q' = q*cos + rotate_half(q)*sin on the patch tokens): the partner of element d is d +- 32.  The tables satisfy
-// cos[d] == cos[d+32] (angles tiled twice), so one (cos, sin) octet serves both halves.
-__device__ __forceinline__ void rope8(u32x4 &lo, u32x4 &hi, const float4 &c0, const float4 &c1, const float4 &s0, const float4 &s1) {
-    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    bf16x8 a = __builtin_bit_cast(bf16x8, lo), b = __builtin_bit_cast(bf16x8, hi);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float x0 = (float)a[j], x1 = (float)b[j];
-        a[j] = (bf16)(x0 * cs[j] - x1 * sn[j]);
-        b[j] = (bf16)(x1 * cs[j] + x0 * sn[j]);
-    }
-    lo = __builtin_bit_cast(u32x4, a);
-    hi = __builtin_bit_cast(u32x4, b);
-}
-
-// K/V preparation, once per (frame, head, 64-token tile) instead of once per query tile inside attention:
-// RoPE on K in place, and V written transposed + zero padded: vt (B, H, 64, Tp), Tp = 64 * ceil(T / 64).
-__global__ __launch_bounds__(256) void kv_prep_kernel(bf16 *__restrict__ k, const bf16 *__restrict__ v, bf16 *__restrict__ vt,
-                                                       const float *__restrict__ cosb, const float *__restrict__ sinb, int T, int Tp) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];      // [token][d], 66-element rows
-    const int tid = threadIdx.x, head = blockIdx.y;
-    const long long f = blockIdx.z;
-    const long long bh = (f * VH + head) * (long long)T;
-    const int t0 = blockIdx.x * 64;
-    const int key = t0 + (tid >> 2), pr = tid & 3;
-    if (key < T) {
-        const long long off = (bh + key) * VHD + pr * 8;
-        if (key >= VPREFIX) {
-            u32x4 lo = *reinterpret_cast<const u32x4 *>(k + off), hi = *reinterpret_cast<const u32x4 *>(k + off + 32);
-            const float *c = cosb + (long long)(key - VPREFIX) * VHD + pr * 8, *sn = sinb + (long long)(key - VPREFIX) * VHD + pr * 8;
-            rope8(lo, hi, *reinterpret_cast<const float4 *>(c), *reinterpret_cast<const float4 *>(c + 4),
-                  *reinterpret_cast<const float4 *>(sn), *reinterpret_cast<const float4 *>(sn + 4));
-            *reinterpret_cast<u32x4 *>(k + off) = lo;
-            *reinterpret_cast<u32x4 *>(k + off + 32) = hi;
-        }
-    }
-    // V tile -> LDS (natural), then each thread gathers 16 tokens of one d and writes two 16-B pieces of vt[d][t0..]
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int c = tid + 256 * i, tk = c >> 3, dc = c & 7;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (t0 + tk < T) val = *reinterpret_cast<const u32x4 *>(v + (bh + t0 + tk) * VHD + dc * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) tile[tk * 66 + dc * 8 + j] = (unsigned short)(val[j >> 1] >> (16 * (j & 1)));
-    }
-    __syncthreads();
-    {
-        const int d = tid >> 2, part = tid & 3;
-        u32x4 o[2];
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const unsigned a = tile[(part * 16 + j) * 66 + d], b = tile[(part * 16 + j + 1) * 66 + d];
-            o[j >> 3][(j >> 1) & 3] = a | (b << 16);
-        }
-        bf16 *dst = vt + ((f * VH + head) * VHD + d) * (long long)Tp + t0 + part * 16;
-        *reinterpret_cast<u32x4 *>(dst) = o[0];
-        *reinterpret_cast<u32x4 *>(dst + 8) = o[1];
-    }
-}
-
 // Flash-style attention, one workgroup = 128 queries of one (frame, head), 4 waves x 32 queries, keys in tiles of 64.
-// q arrives pre-scaled by log2(e)/sqrt(64) (QKV epilogue), k already rotated, vt already transposed.
-__global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, const bf16 *__restrict__ k,
-                                                    const bf16 *__restrict__ vt, const float *__restrict__ cosb,
-                                                    const float *__restrict__ sinb, bf16 *__restrict__ o, int T, int Tp) {
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AKT * KLD];
-    __shared__ __attribute__((aligned(16))) bf16 Vt[2][VHD * VLD];
-    __shared__ __attribute__((aligned(16))) float bc[4][32];
+// q, k arrive rotated (RoPE) and q pre-scaled by log2(e)/sqrt(64) from the QKV epilogue; v is in its natural (B, H, T, 64)
+// layout.  Everything per query lives on ONE lane pair (r, r + 32):
+//   S^T = K . Q^T   (keys on accumulator rows, the query on the lane)  -> max / exp2 / row sums are lane-local;
+//   O^T = V^T . P^T (d on accumulator rows, the query on the lane): P^T is fed to the MFMA straight from the S^T
+//   accumulator registers (B operand), V^T fragments come from the natural-layout V tile by ds_read_b64_tr_b16 (the
+//   hardware transposing LDS read; tile rows of 128 B with the 16-byte chunk index XOR-ed by 4 ((key >> 1) & 1) - conflict
+//   free), and the rescaling of O is lane-local too - no LDS broadcast of row statistics.
+// Softmax runs with a FIXED per-query shift m0 (the first tile's maximum, folded into the MFMA chain as its initial
+// accumulator: no subtraction per score): exp2(s - m0) cannot overflow unless a later score exceeds m0 by > 64 - a guard
+// (one max per two scores, lane-local) then rescales O, the row sum and the shift; that branch is taken ~never for
+// LayerNorm-ed ViT activations, but it keeps the kernel exact for any input.  VALU work per score: exp2, add, half a
+// convert, half a max - the kernel is VALU-bound at head dim 64 (one exp2 per 256 FLOP), so this count IS its speed.
+constexpr int AQ = 128, AKT = 64, KLD = 72;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 ld_tr2(const char *p0, const char *p1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 c = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, c);
+}
+
+__global__ __launch_bounds__(256, 3) void attn_kernel(const bf16 *__restrict__ q, const bf16 *__restrict__ k, const bf16 *__restrict__ v,
+                                                      bf16 *__restrict__ o, int T) {
+    __shared__ __attribute__((aligned(16))) char att_smem[2 * AKT * KLD * 2 + 2 * AKT * VHD * 2];     // K ring 18 KB + V ring 16 KB
+    bf16 *Ks = reinterpret_cast<bf16 *>(att_smem);
+    char *Vs = att_smem + 2 * AKT * KLD * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y;
     const long long f = blockIdx.z;
     const long long bh = (f * VH + head) * (long long)T;
-    const bf16 *vth = vt + (f * VH + head) * (long long)VHD * Tp;
     const int i0 = blockIdx.x * AQ + wave * 32;
     const int qi = min(i0 + r, T - 1);
 
     bf16x8 qf[4];
-    {
-        u32x4 qraw[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) qraw[ks] = *reinterpret_cast<const u32x4 *>(q + (bh + qi) * VHD + ks * 16 + 8 * h);
-        if (qi >= VPREFIX) {   // element d of this lane's fragment ks is 16*ks + 8h + j; its partner d + 32 sits in fragment ks + 2
-            const float *c = cosb + (long long)(qi - VPREFIX) * VHD + 8 * h, *sn = sinb + (long long)(qi - VPREFIX) * VHD + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-                rope8(qraw[ks], qraw[ks + 2], *reinterpret_cast<const float4 *>(c + 16 * ks), *reinterpret_cast<const float4 *>(c + 16 * ks + 4),
-                      *reinterpret_cast<const float4 *>(sn + 16 * ks), *reinterpret_cast<const float4 *>(sn + 16 * ks + 4));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) qf[ks] = __builtin_bit_cast(bf16x8, qraw[ks]);
-    }
+    for (int ks = 0; ks < 4; ks++) qf[ks] = *reinterpret_cast<const bf16x8 *>(q + (bh + qi) * VHD + ks * 16 + 8 * h);
 
-    // staging: 512 16-byte pieces of K (key rows) and 512 of V^T (d rows) per tile, two of each per thread
+    // staging: thread (row = tid >> 2, c4 = tid & 3) moves the 16-byte pieces c4 and c4 + 4 of key row `row` of K and V
+    const int srow = tid >> 2, c4 = tid & 3;
+    const int vswz = 4 * ((srow >> 1) & 1);
     u32x4 rk[2], rv[2];
 #define A_LOAD(kt)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
-        const int c = tid + 256 * i, row = c >> 3, pc = c & 7;                                       \
-        const int key = (kt) * AKT + row;                                                            \
+    {                                                                                                \
+        const int key = (kt) * AKT + srow;                                                           \
         const unsigned msk = key < T ? 0xffffffffu : 0u;                                             \
-        rk[i] = *reinterpret_cast<const u32x4 *>(k + (bh + min(key, T - 1)) * VHD + pc * 8) & msk;   \
-        rv[i] = *reinterpret_cast<const u32x4 *>(vth + (long long)row * Tp + (kt) * AKT + pc * 8);   \
+        const long long off = (bh + min(key, T - 1)) * VHD + c4 * 8;                                 \
+        rk[0] = *reinterpret_cast<const u32x4 *>(k + off) & msk;                                     \
+        rk[1] = *reinterpret_cast<const u32x4 *>(k + off + 32) & msk;                                \
+        rv[0] = *reinterpret_cast<const u32x4 *>(v + off) & msk;                                     \
+        rv[1] = *reinterpret_cast<const u32x4 *>(v + off + 32) & msk;                                \
     }
 #define A_STORE(buf)                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 2; i++) {                                                  \
-        const int c = tid + 256 * i, row = c >> 3, pc = c & 7;                                       \
-        *reinterpret_cast<u32x4 *>(&Ks[buf][row * KLD + pc * 8]) = rk[i];                            \
-        unsigned long long *vd = reinterpret_cast<unsigned long long *>(&Vt[buf][row * VLD + pc * 8]); \
-        vd[0] = (unsigned long long)rv[i][0] | ((unsigned long long)rv[i][1] << 32);                 \
-        vd[1] = (unsigned long long)rv[i][2] | ((unsigned long long)rv[i][3] << 32);                 \
+    {                                                                                                \
+        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + srow * KLD + c4 * 8) = rk[0];            \
+        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + srow * KLD + c4 * 8 + 32) = rk[1];       \
+        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + srow * 128 + ((c4 ^ vswz) << 4)) = rv[0];        \
+        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + srow * 128 + (((c4 + 4) ^ vswz) << 4)) = rv[1];  \
+    }
+    // transposing V reads: lane (group G = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3) addresses key row (.. + q4),
+    // d = 32 dt + 16 (G & 1) + 4 p4; it receives d = 32 dt + (lane & 31), keys (.. + 0..3)
+    int voff[2];
+    {
+        const int q4 = (lane >> 2) & 3, p4 = lane & 3, dl = 16 * ((lane >> 4) & 1) + 4 * p4, sw = 4 * ((q4 >> 1) & 1);
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) voff[dt] = (4 * h + q4) * 128 + ((((dl + 32 * dt) >> 3) ^ sw) << 4) + (dl & 7) * 2;
     }
 
-    f32x16 oacc[2];
+    f32x16 oacc[2], negm;
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) oacc[dt][e] = 0.0f;
-    float m = -INFINITY, l = 0.0f;
+    for (int e = 0; e < 16; e++) oacc[0][e] = oacc[1][e] = negm[e] = 0.0f;
+    float l = 0.0f;
 
     const int ntile = (T + AKT - 1) / AKT;
     A_LOAD(0);
@@ -459,14 +706,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
     __syncthreads();
     for (int kt = 0; kt < ntile; kt++) {
         if (kt + 1 < ntile) A_LOAD(kt + 1);
-        const bf16 *Kb = &Ks[kt & 1][0];
-        const bf16 *Vb = &Vt[kt & 1][0];
-        // S^T tiles: rows = keys, cols = queries (already in the log2 domain)
+        const bf16 *Kb = Ks + (kt & 1) * AKT * KLD;
+        const char *Vb = Vs + (kt & 1) * AKT * 128;
+        // S^T tiles: rows = keys, cols = queries, in the log2 domain, minus the query's shift (initial accumulator)
         f32x16 st[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) st[j][e] = 0.0f;
+            st[j] = negm;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const bf16x8 ka = *reinterpret_cast<const bf16x8 *>(Kb + (j * 32 + r) * KLD + ks * 16 + 8 * h);
@@ -483,54 +729,41 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
         float mt = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
         for (int e = 1; e < 16; e++) mt = fmaxf(mt, fmaxf(st[0][e], st[1][e]));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float mn = fmaxf(m, mt);
-        float rs = 0.0f;
+        if (__any(mt > 64.0f) || kt == 0) {
+            // (re)centre this query: lanes r and r + 32 hold the two key halves of the same query and must agree
+            const float d = fmaxf(mt, __shfl_xor(mt, 32));
+            const float a = __builtin_amdgcn_exp2f(-d);
+            l *= a;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                oacc[0][e] *= a;
+                oacc[1][e] *= a;
+                negm[e] -= d;
+                st[0][e] -= d;
+                st[1][e] -= d;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float p = __builtin_amdgcn_exp2f(st[j][e] - mn);
+                const float p = __builtin_amdgcn_exp2f(st[j][e]);
                 st[j][e] = p;
-                rs += p;
+                l += p;
             }
-        rs += __shfl_xor(rs, 32);
-        if (__any(mn != m)) {
-            // rescale O: alpha lives on the query's lane, O rows are queries -> broadcast through LDS (wave-local)
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
-            l *= alpha;
-            if (h == 0) bc[wave][r] = alpha;
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS write has landed
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const float4 a4 = *reinterpret_cast<const float4 *>(&bc[wave][8 * g4 + 4 * h]);
-#pragma unroll
-                for (int dt = 0; dt < 2; dt++) {
-                    oacc[dt][4 * g4 + 0] *= a4.x;
-                    oacc[dt][4 * g4 + 1] *= a4.y;
-                    oacc[dt][4 * g4 + 2] *= a4.z;
-                    oacc[dt][4 * g4 + 3] *= a4.w;
-                }
-            }
-            m = mn;
-        }
-        l += rs;
-        // P.V: P^T tile registers 8*s2..8*s2+7 are the A fragment of k-step s2 (key order 16*s2 + 8*(j>>2) + 4h + (j&3))
+        // O^T += V^T . P^T: P^T registers 8 s2 .. 8 s2 + 7 of tile j are the B fragment of k-step s2; its element e is key
+        // 32 j + 16 s2 + 8 (e >> 2) + 4 h + (e & 3), which is exactly what two transposing reads of 4 key rows deliver
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
-                bf16x8 pa;
+                bf16x8 pb;
 #pragma unroll
-                for (int e = 0; e < 8; e++) pa[e] = (bf16)st[j][8 * s2 + e];
+                for (int e = 0; e < 8; e++) pb[e] = (bf16)st[j][8 * s2 + e];
 #pragma unroll
                 for (int dt = 0; dt < 2; dt++) {
-                    const bf16 *vp = Vb + (dt * 32 + r) * VLD + j * 32 + 16 * s2 + 4 * h;
-                    const bf16x4 v0 = *reinterpret_cast<const bf16x4 *>(vp), v1 = *reinterpret_cast<const bf16x4 *>(vp + 8);
-                    bf16x8 vb;
-                    vb[0] = v0[0]; vb[1] = v0[1]; vb[2] = v0[2]; vb[3] = v0[3];
-                    vb[4] = v1[0]; vb[5] = v1[1]; vb[6] = v1[2]; vb[7] = v1[3];
-                    oacc[dt] = mfma_bf16(pa, vb, oacc[dt]);
+                    const char *vp = Vb + (32 * j + 16 * s2) * 128 + voff[dt];
+                    oacc[dt] = mfma_bf16(ld_tr2(vp, vp + 8 * 128), pb, oacc[dt]);
                 }
             }
         if (kt + 1 < ntile) A_STORE((kt + 1) & 1);
@@ -538,37 +771,64 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16 *__restrict__ q, c
     }
 #undef A_LOAD
 #undef A_STORE
-    // normalise by the row sums (broadcast like alpha) and write (B, T, 384) bf16
-    if (h == 0) bc[wave][r] = 1.0f / l;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // normalise, transpose through LDS (wave-private 32 x 144-byte tile in the K ring: every wave is past its last read) and
+    // write (B, T, 384) bf16 as full 128-byte lines
+    const float inv = 1.0f / (l + __shfl_xor(l, 32));
+    char *stg = att_smem + wave * 32 * 144;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(&bc[wave][8 * g4 + 4 * h]);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int row = i0 + 8 * g4 + 4 * h + u;
-            if (row < T) {
+        for (int g = 0; g < 4; g++) {
+            uint2 ov;
+            ov.x = pack_bf16x2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+            ov.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+            *reinterpret_cast<uint2 *>(stg + r * 144 + 64 * dt + 16 * g + 8 * h) = ov;
+        }
+    {
+        const int q8 = lane >> 3, p8 = lane & 7;
 #pragma unroll
-                for (int dt = 0; dt < 2; dt++)
-                    o[((long long)f * T + row) * VD + head * VHD + dt * 32 + r] = (bf16)(oacc[dt][4 * g4 + u] * av[u]);
-            }
+        for (int i = 0; i < 4; i++) {
+            const u32x4 val = *reinterpret_cast<const u32x4 *>(stg + (8 * i + q8) * 144 + 16 * p8);
+            const int row = i0 + 8 * i + q8;
+            if (row < T) *reinterpret_cast<u32x4 *>(o + ((long long)f * T + row) * VD + head * VHD + 8 * p8) = val;
         }
     }
 }
 
-// A-resident persistent GEMM: one workgroup per CU walks (row tile, column group) items
-template <int S, class Epi>
-void launch_ares(const bf16 *A, const bf16 *Wp, long long M, int N, int K, Epi epi, hipStream_t st) {
-    const int n_groups = N / (128 * S), n_tiles = (int)((M + RM128 - 1) / RM128), n_items = n_tiles * n_groups;
-    const int slots = MT <= 3 ? 256 * ARES_OCC : 256;                  // persistent workgroups: 3 per CU at 64 rows, 1 at 128
-    const int grid = n_tiles < slots ? n_tiles : slots;
-    hipLaunchKernelGGL((gemm_ares_kernel<S, Epi>), dim3(grid), dim3(256), 0, st, A, Wp, (int)M, N, K, n_items, n_groups, epi);
+int g_rt_dbg = 0;
+// row-tile GEMM launch: one workgroup per (128-row tile, half of the 192-column tiles)
+template <int KC, int NTP, class Pro, class Epi>
+void launch_rt(Pro pro, const bf16 *Wp, long long M, int N, Epi epi, hipStream_t st) {
+    const int parts = N / RT_NT / NTP, n_tiles = (int)((M + RT_BM - 1) / RT_BM);
+    hipLaunchKernelGGL((gemm_rt_kernel<KC, NTP, Pro, Epi>), dim3((n_tiles + 7) / 8 * 8 * parts), dim3(256),
+                       RT_LDS_BYTES + 4 * (Pro::VEC + RT_NT * NTP + epi.extra_floats()), st, pro, Wp, (int)M, parts, epi, g_rt_dbg);
 }
 
 size_t ws_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
+
+extern "C" int sslam_vit_pack_linear_host(const float *w, int n_out, int k_in, uint16_t *out) {
+    if (!w || !out || n_out <= 0 || k_in <= 0) return SSLAM_E_INVALID;
+    if (n_out % RT_NT || k_in % 384) return SSLAM_E_UNSUPPORTED;
+    const int ksteps = k_in / 16;
+    for (int n = 0; n < n_out; n++)
+        for (int k = 0; k < k_in; k++) {
+            const float f = w[(size_t)n * k_in + k];
+            uint32_t u;
+            memcpy(&u, &f, 4);
+            const uint16_t b = (u & 0x7fffffffu) > 0x7f800000u ? (uint16_t)((u >> 16) | 0x40) : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            const size_t frag = ((size_t)(n / RT_NT) * ksteps + k / 16) * RT_SL + (n % RT_NT) / 32;
+            out[(frag * 64 + ((k % 16) / 8) * 32 + n % 32) * 8 + k % 8] = b;      // round-to-nearest-even bf16, NaN kept
+        }
+    return SSLAM_OK;
+}
+
+#ifdef SSLAM_RT_PROBE
+extern "C" int sslam_probe_vit(unsigned long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rt_probe), sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" long long sslam_vit_workspace_bytes(int n_frames, int size) {
     if (n_frames <= 0 || size <= 0 || size % VPATCH) return SSLAM_E_INVALID;
@@ -577,8 +837,8 @@ extern "C" long long sslam_vit_workspace_bytes(int n_frames, int size) {
     b += ws_align(rows * VD * 4);                 // x   fp32 residual stream
     b += ws_align(rows * VD * 2);                 // y   bf16 LN output / attention output
     b += ws_align(rows * VD * 2 * 3);             // q, k, v bf16
-    b += ws_align((long long)n_frames * VD * ((T + 63) / 64 * 64) * 2);   // v transposed + padded
     b += ws_align(rows * VMLP * 2);               // h   bf16 MLP hidden (also the patch matrix)
+    b += ws_align(rows * 16);                     // LayerNorm partial sums: (sum, sumsq) x 2 column halves per row
     return (long long)b;
 }
 
@@ -591,38 +851,43 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
     const long long rows = (long long)n_frames * T, prow = (long long)n_frames * cells;
     if (rows * VMLP > 0x7fffffffLL * 64) return SSLAM_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    { const char *e = getenv("SSLAM_RT_DBG"); g_rt_dbg = e ? atoi(e) : 0; }
     char *p = (char *)workspace;
     float *x = (float *)p;            p += ws_align(rows * VD * 4);
     bf16 *y = (bf16 *)p;              p += ws_align(rows * VD * 2);
     bf16 *q = (bf16 *)p;              bf16 *k = q + rows * VD, *v = k + rows * VD;   p += ws_align(rows * VD * 2 * 3);
-    const int Tp = (T + 63) / 64 * 64;
-    bf16 *vt = (bf16 *)p;             p += ws_align((long long)n_frames * VD * Tp * 2);
-    bf16 *hbuf = (bf16 *)p;
+    bf16 *hbuf = (bf16 *)p;          p += ws_align(rows * VMLP * 2);
+    float2 *stats = (float2 *)p;
 
     // patch embedding + prefix tokens
     {
         const long long items = prow * 96;
         hipLaunchKernelGGL(im2patch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, images_chw, size, items, hbuf);
         g_sslam_launches++;
-        launch_ares<1>(hbuf, (const bf16 *)w->patch_w, prow, VD, 768, EpiPatch{w->patch_b, x, cells, T}, st);
+        launch_rt<2, 1>(ProBf16{hbuf, 768}, (const bf16 *)w->patch_w, prow, VD, EpiPatch{w->patch_b, x, stats, cells, T}, st);
         g_sslam_launches++;
-        const long long pi = (long long)n_frames * VPREFIX * VD;
-        hipLaunchKernelGGL(prefix_rows_kernel, dim3((unsigned)((pi + 255) / 256)), dim3(256), 0, st, w->prefix, T, pi, x);
+        hipLaunchKernelGGL(prefix_rows_kernel, dim3(n_frames * VPREFIX), dim3(64), 0, st, w->prefix, T, x, stats);
         g_sslam_launches++;
     }
-    const unsigned ln_grid = (unsigned)((rows + 3) / 4);
+    const float4 *st4 = (const float4 *)stats;
+    int rt_stop = 0;
+#ifdef SSLAM_RT_PROBE
+    { const char *e = getenv("SSLAM_RT_STOP"); rt_stop = e ? atoi(e) : 0; }
+#endif
     for (int L = 0; L < VLAYERS; L++) {
         const sslam_vit_layer_t &ly = w->layer[L];
-        hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, (void *)y);
-        launch_ares<1>(y, (const bf16 *)ly.wqkv, rows, 3 * VD, VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st);
-        hipLaunchKernelGGL(kv_prep_kernel, dim3(Tp / 64, VH, n_frames), dim3(256), 0, st, k, v, vt, w->rope_cos, w->rope_sin, T, Tp);
-        hipLaunchKernelGGL(attn_kernel, dim3((T + AQ - 1) / AQ, VH, n_frames), dim3(256), 0, st, q, k, vt, w->rope_cos, w->rope_sin, y, T, Tp);
-        launch_ares<1>(y, (const bf16 *)ly.wo, rows, VD, VD, EpiResidual{ly.bo, ly.ls1, x}, st);
-        hipLaunchKernelGGL(ln_rows_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, (void *)y);
-        launch_ares<1>(y, (const bf16 *)ly.wup, rows, VMLP, VD, EpiGelu{ly.bup, hbuf, VMLP}, st);
-        launch_ares<1>(hbuf, (const bf16 *)ly.wdown, rows, VD, VMLP, EpiResidual{ly.bdown, ly.ls2, x}, st);
-        g_sslam_launches += 8;
+        launch_rt<1, 3>(ProLN{x, st4, ly.ln1_g, ly.ln1_b, 1e-5f}, (const bf16 *)ly.wqkv, rows, 3 * VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T, G}, st);
+        if (rt_stop == 1) break;
+        hipLaunchKernelGGL(attn_kernel, dim3((T + AQ - 1) / AQ, VH, n_frames), dim3(256), 0, st, q, k, v, y, T);
+        launch_rt<1, 1>(ProBf16{y, VD}, (const bf16 *)ly.wo, rows, VD, EpiResidual{ly.bo, x, stats}, st);
+        if (rt_stop == 2) break;
+        launch_rt<1, 4>(ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wup, rows, VMLP, EpiGelu{ly.bup, hbuf, VMLP}, st);
+        if (rt_stop == 3) break;
+        launch_rt<4, 1>(ProBf16{hbuf, VMLP}, (const bf16 *)ly.wdown, rows, VD, EpiResidual{ly.bdown, x, stats}, st);
+        if (rt_stop == 4) break;
+        g_sslam_launches += 5;
     }
+    const unsigned ln_grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, (void *)tokens_out);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;

@@ -28,8 +28,8 @@ class SslamHipError(RuntimeError):
 
 
 class VitLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ls1", "ln2_g", "ln2_b", "wup", "bup",
-                                          "wdown", "bdown", "ls2")]
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "wup", "bup",
+                                          "wdown", "bdown")]
 
 
 class VitWeights(C.Structure):
@@ -59,7 +59,7 @@ EXPORTS = [
     "sslam_resample_table_host", "sslam_preprocess_u8", "sslam_bn_tokens", "sslam_selector_saliency",
     "sslam_select_keypoints", "sslam_gather", "sslam_refiner_layout", "sslam_refiner_pack_host", "sslam_refine",
     "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
-    "sslam_vit_workspace_bytes", "sslam_vit_forward",
+    "sslam_vit_pack_linear_host", "sslam_vit_workspace_bytes", "sslam_vit_forward",
     "sslam_f32_to_bf16", "sslam_pack_conv3x3_bf16_host", "sslam_selector_saliency_bf16",
     "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
 ]
@@ -100,6 +100,7 @@ def lib():
         L.sslam_refiner_pack_bf16_host.argtypes = [p, i, p]
         L.sslam_refine_bf16.argtypes = [p, ll, p, i, p, p]
         L.sslam_gather_refine_bf16.argtypes = [p, i, i, p, i, p, i, p, p]
+        L.sslam_vit_pack_linear_host.argtypes = [p, i, i, p]
         L.sslam_vit_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
@@ -373,6 +374,14 @@ def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in
                                       f(w_desc), f(w_sal), f(t_sal), f(t_sim), f(t_int), _dp(matches), _dp(quality),
                                       _dp(count))
     return matches, quality, count
+
+
+def pack_vit_linear(w: np.ndarray) -> np.ndarray:
+    """(n_out, k_in) fp32 nn.Linear weight -> uint16 array of bf16 bit patterns in the ViT GEMM's streaming order."""
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(w.size, np.uint16)
+    _check(lib().sslam_vit_pack_linear_host(w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data), "vit_pack_linear")
+    return out
 
 
 def vit_workspace_bytes(n_frames: int, size: int) -> int:

@@ -26,15 +26,17 @@ class HipViT:
         self.w.patch_w = bf(vit.patch_embed.weight.reshape(384, 768))
         self.w.patch_b = f32(vit.patch_embed.bias)
         self.w.prefix = f32(torch.cat([vit.cls_token[0], vit.register_tokens[0]], dim=0))
+        qs = 0.125 * 1.4426950408889634          # 1/sqrt(64) and the exp2 domain of the softmax, folded into the q rows
         for i, b in enumerate(vit.blocks):
             ly = self.w.layer[i]
             ly.ln1_g, ly.ln1_b = f32(b.norm1.weight), f32(b.norm1.bias)
-            ly.wqkv = bf(torch.cat([b.q_proj.weight, b.k_proj.weight, b.v_proj.weight], dim=0))
-            ly.bqkv = f32(torch.cat([b.q_proj.bias, torch.zeros_like(b.q_proj.bias), b.v_proj.bias]))
-            ly.wo, ly.bo, ly.ls1 = bf(b.o_proj.weight), f32(b.o_proj.bias), f32(b.ls1)
+            ly.wqkv = bf(torch.cat([b.q_proj.weight * qs, b.k_proj.weight, b.v_proj.weight], dim=0))
+            ly.bqkv = f32(torch.cat([b.q_proj.bias * qs, torch.zeros_like(b.q_proj.bias), b.v_proj.bias]))
+            # LayerScale folded into the projections that feed the residual stream: ls * (W a + b) = (ls W) a + ls b
+            ly.wo, ly.bo = bf(b.o_proj.weight * b.ls1[:, None]), f32(b.o_proj.bias * b.ls1)
             ly.ln2_g, ly.ln2_b = f32(b.norm2.weight), f32(b.norm2.bias)
             ly.wup, ly.bup = bf(b.up_proj.weight), f32(b.up_proj.bias)
-            ly.wdown, ly.bdown, ly.ls2 = bf(b.down_proj.weight), f32(b.down_proj.bias), f32(b.ls2)
+            ly.wdown, ly.bdown = bf(b.down_proj.weight * b.ls2[:, None]), f32(b.down_proj.bias * b.ls2)
         self.w.norm_g, self.w.norm_b = f32(vit.norm.weight), f32(vit.norm.bias)
 
     def _hold(self, t):
@@ -42,10 +44,9 @@ class HipViT:
         return t.data_ptr()
 
     def _frag(self, w):
-        """(N, K) nn.Linear weight -> bf16 in MFMA B-fragment order [N/32][K/16][2][32][8] (csrc/vit.hip gemm_ares_kernel)."""
-        n, k = w.shape
-        t = w.detach().to(self.device, torch.bfloat16).reshape(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4)
-        return self._hold(t.contiguous())
+        """(N, K) nn.Linear weight -> bf16 in the streaming order of csrc/vit.hip gemm_rt_kernel (packed by the library)."""
+        packed = lib.pack_vit_linear(w.detach().float().cpu().numpy())
+        return self._hold(torch.from_numpy(packed).to(self.device))
 
     def _f32(self, t):
         return self._hold(t.detach().to(self.device, torch.float32).contiguous())

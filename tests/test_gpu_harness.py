@@ -103,7 +103,7 @@ def test_sequence_matcher_extract_from_png(T, tmp_path):
     sm = SequenceMatcher(bb, ssd, rsd, device="cuda")
     before = lib.launch_count()
     f1, f2 = sm.extract(paths[0]), sm.extract(paths[1])
-    assert lib.launch_count() >= before + 2 * 90, "the HIP ViT and the HIP stages must have served extract()"
+    assert lib.launch_count() >= before + 2 * 60, "the HIP ViT and the HIP stages must have served extract()"
     assert set(f1) == {"image", "saliency", "keypoints_pixel", "scores", "intensity", "descriptors"}
     assert f1["saliency"].shape == (28, 28) and f1["keypoints_pixel"].shape == (500, 2) and f1["scores"].shape == (500,)
     assert f1["intensity"].shape == (500,) and f1["descriptors"].shape == (500, 128)

@@ -449,4 +449,4 @@ def test_pipeline_with_hip_vit_end_to_end(T, hip):
     before = hip.launch_count()
     with T.no_grad():
         f = bb(pipe.preprocess(imgs[:2]))
-    assert f.shape == (2, 28, 28, 384) and hip.launch_count() >= before + 90      # 12 layers x 8 launches
+    assert f.shape == (2, 28, 28, 384) and hip.launch_count() >= before + 60      # 12 layers x (5 or 6) launches
