@@ -291,13 +291,25 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
                     issued++;
                 }
                 const char *bb = rt_smem + buf * RT_GROUP_BYTES + lane * 16;
-#pragma unroll
-                for (int kk = 0; kk < RT_GK; kk++)
-#pragma unroll
-                    for (int s = 0; s < RT_SL; s++) {
-                        const bf16x8 w = *reinterpret_cast<const bf16x8 *>(bb + (kk * RT_SL + s) * 1024);
-                        acc[s] = mfma_bf16(w, a[kg * RT_GK + kk], acc[s]);
-                    }
+                // fragment triples, software-pipelined by hand: the three ds_read_b128 of triple i + 1 are issued BEFORE the
+                // three MFMAs of triple i (96 cycles of matrix work cover the LDS latency); left alone hipcc reads two
+                // fragments, waits lgkmcnt(0), issues two MFMAs - the pipe idles through every LDS round trip
+                bf16x8 wa[3], wb[3];
+#define RT_LD3(dst, i_) _Pragma("unroll") for (int t = 0; t < 3; t++) dst[t] = *reinterpret_cast<const bf16x8 *>(bb + ((i_) * 3 + t) * 1024);
+#define RT_MM3(src, i_)                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 3; t++) acc[((i_) & 1) * 3 + t] = mfma_bf16(src[t], a[kg * RT_GK + (i_) / 2], acc[((i_) & 1) * 3 + t]); \
+    __builtin_amdgcn_sched_barrier(0);
+                RT_LD3(wa, 0)
+                RT_LD3(wb, 1) RT_MM3(wa, 0)
+                RT_LD3(wa, 2) RT_MM3(wb, 1)
+                RT_LD3(wb, 3) RT_MM3(wa, 2)
+                RT_LD3(wa, 4) RT_MM3(wb, 3)
+                RT_LD3(wb, 5) RT_MM3(wa, 4)
+                RT_LD3(wa, 6) RT_MM3(wb, 5)
+                RT_LD3(wb, 7) RT_MM3(wa, 6)
+                RT_MM3(wb, 7)
+#undef RT_LD3
+#undef RT_MM3
                 buf ^= 1;
                 RT_STAMP(t_w2);
                 RT_ACC(p_mma, t_w2, t_w1);
@@ -671,13 +683,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const bf16 *__restrict__ q
     u32x4 rk[2], rv[2];
 #define A_LOAD(kt)                                                                                   \
     {                                                                                                \
-        const int key = (kt) * AKT + srow;                                                           \
-        const unsigned msk = key < T ? 0xffffffffu : 0u;                                             \
-        const long long off = (bh + min(key, T - 1)) * VHD + c4 * 8;                                 \
-        rk[0] = *reinterpret_cast<const u32x4 *>(k + off) & msk;                                     \
-        rk[1] = *reinterpret_cast<const u32x4 *>(k + off + 32) & msk;                                \
-        rv[0] = *reinterpret_cast<const u32x4 *>(v + off) & msk;                                     \
-        rv[1] = *reinterpret_cast<const u32x4 *>(v + off + 32) & msk;                                \
+        /* keys beyond T re-read row T - 1 (finite data): their scores are set to -inf below, so P = 0 */   \
+        const long long off = (bh + min((kt) * AKT + srow, T - 1)) * VHD + c4 * 8;                   \
+        rk[0] = *reinterpret_cast<const u32x4 *>(k + off);                                           \
+        rk[1] = *reinterpret_cast<const u32x4 *>(k + off + 32);                                      \
+        rv[0] = *reinterpret_cast<const u32x4 *>(v + off);                                           \
+        rv[1] = *reinterpret_cast<const u32x4 *>(v + off + 32);                                      \
     }
 #define A_STORE(buf)                                                                                 \
     {                                                                                                \
@@ -726,9 +737,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const bf16 *__restrict__ q
                 for (int e = 0; e < 16; e++)
                     if (kt * AKT + j * 32 + crow(e, h) >= T) st[j][e] = -INFINITY;
         }
-        float mt = fmaxf(st[0][0], st[1][0]);
+        float mt = st[0][0];           // v_max3 by hand: fmaxf() on MFMA outputs costs two canonicalising v_max each
 #pragma unroll
-        for (int e = 1; e < 16; e++) mt = fmaxf(mt, fmaxf(st[0][e], st[1][e]));
+        for (int e = 0; e < 16; e++) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mt) : "v"(st[0][e]), "v"(st[1][e]));
         if (__any(mt > 64.0f) || kt == 0) {
             // (re)centre this query: lanes r and r + 32 hold the two key halves of the same query and must agree
             const float d = fmaxf(mt, __shfl_xor(mt, 32));
