@@ -39,37 +39,41 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f3
 METRIC = "frames/sec extract+match on TUM 640x480; match-index bit-exact vs CPU ref"
 
 
-def synth_sequence(n, h, w, grid, device, seed):
-    """Device-side synthetic sequence: smooth-plus-texture uint8 frames related by small shifts, and
-    N(0.5, 3^2) token fields sliding over a larger field (+ per-frame noise) so that real mutual matches exist."""
+def synth_sequence(n_total, lo, hi, h, w, grid, device, seed):
+    """Frames [lo, hi) of ONE device-side synthetic sequence of n_total frames: smooth-plus-texture uint8 frames
+    related by small shifts, and N(0.5, 3^2) token fields sliding over a larger field (+ per-frame noise) so that real mutual
+    matches exist.  The canvas, the token field and the random walk depend on `seed` only and the per-frame noise on
+    (seed, frame index), so every rank of a sharded run generates ITS block of the same sequence: the pairs that straddle a
+    shard boundary are consecutive frames like any other pair."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rng = np.random.Generator(np.random.PCG64(seed))
-    pad = 32
+    pad, tp, n = 32, 6, hi - lo
     base = torch.randn((1, 3, h + 2 * pad, w + 2 * pad), generator=g, device=device)
     low = base
     for _ in range(3):
         low = torch.nn.functional.avg_pool2d(low, 25, stride=1, padding=12)
     low = low / low.std()
     canvas = 128.0 + 60.0 * low + 25.0 * torch.randn(base.shape, generator=g, device=device)
+    field = torch.randn((grid + 2 * tp, grid + 2 * tp, 384), generator=g, device=device) * 3.0 + 0.5
+    steps, tsteps = rng.integers(-4, 5, size=(n_total, 2)), rng.integers(-1, 2, size=(n_total, 2))
     imgs = torch.empty((n, h, w, 3), dtype=torch.uint8, device=device)
-    steps = rng.integers(-4, 5, size=(n, 2))
+    toks = torch.empty((n, 5 + grid * grid, 384), dtype=torch.float32, device=device)
     ox = oy = pad
-    for i in range(n):
+    tx = ty = tp
+    gf = torch.Generator(device=device)
+    for i in range(hi):
         ox = int(np.clip(ox + steps[i, 0], 0, 2 * pad))
         oy = int(np.clip(oy + steps[i, 1], 0, 2 * pad))
-        win = canvas[0, :, oy:oy + h, ox:ox + w] + torch.randint(-6, 7, (3, h, w), generator=g, device=device)
-        imgs[i] = win.clamp(0, 255).round().permute(1, 2, 0).to(torch.uint8)
-    tp = 6
-    field = torch.randn((grid + 2 * tp, grid + 2 * tp, 384), generator=g, device=device) * 3.0 + 0.5
-    toks = torch.empty((n, 5 + grid * grid, 384), dtype=torch.float32, device=device)
-    tsteps = rng.integers(-1, 2, size=(n, 2))
-    ox = oy = tp
-    for i in range(n):
-        ox = int(np.clip(ox + tsteps[i, 0], 0, 2 * tp))
-        oy = int(np.clip(oy + tsteps[i, 1], 0, 2 * tp))
-        toks[i, :5] = torch.randn((5, 384), generator=g, device=device) * 3.0 + 0.5
-        toks[i, 5:] = (field[oy:oy + grid, ox:ox + grid] + 0.35 * torch.randn((grid, grid, 384), generator=g, device=device)).reshape(-1, 384)
+        tx = int(np.clip(tx + tsteps[i, 0], 0, 2 * tp))
+        ty = int(np.clip(ty + tsteps[i, 1], 0, 2 * tp))
+        if i < lo:
+            continue
+        gf.manual_seed(seed * 1000003 + i)
+        win = canvas[0, :, oy:oy + h, ox:ox + w] + torch.randint(-6, 7, (3, h, w), generator=gf, device=device)
+        imgs[i - lo] = win.clamp(0, 255).round().permute(1, 2, 0).to(torch.uint8)
+        toks[i - lo, :5] = torch.randn((5, 384), generator=gf, device=device) * 3.0 + 0.5
+        toks[i - lo, 5:] = (field[ty:ty + grid, tx:tx + grid] + 0.35 * torch.randn((grid, grid, 384), generator=gf, device=device)).reshape(-1, 384)
     return imgs, toks
 
 
@@ -163,7 +167,7 @@ def main():
     import synth
     from sslam_amd import lib
     from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
-    from sslam_amd.shard import ShardedSequenceRunner
+    from sslam_amd.shard import ShardedSequenceRunner, shard_bounds
 
     n, h, w, size, K = WORKLOADS[args.workload]
     if args.frames:
@@ -172,7 +176,9 @@ def main():
     cfg = ExtractorConfig(input_size=size, num_keypoints=K)
     ssd, rsd = synth.selector_state(0), synth.refiner_state(0)
     pipe = SequencePipeline(cfg, ssd, rsd, device=dev)
-    imgs, toks = synth_sequence(n, h, w, grid, dev, seed=1234 + rank)
+    # one sequence of n * world frames, cut into contiguous blocks (shard_bounds); this rank generates its own block
+    lo, hi = shard_bounds(n * world, world, rank)
+    imgs, toks = synth_sequence(n * world, lo, hi, h, w, grid, dev, seed=1234)
     runner = ShardedSequenceRunner(lambda t, im: pipe.extract(t, im), pipe.match, spacing=cfg.spacing)
 
     # per-stage HIP events on the launch stream (torch's current stream is the one handed to the C ABI)
@@ -205,7 +211,7 @@ def main():
     runner.extract_fn, runner.match_fn = extract_staged, match_staged
 
     def step():
-        return runner.run(toks, imgs)
+        return runner.run(toks, imgs, first_frame=lo)
 
     def fence():
         if world > 1:
@@ -245,10 +251,33 @@ def main():
         cells_ = grid * grid
         t_ = cells_ + 5
         vit_flop = 12 * (t_ * 384 * 1152 * 2 + 2 * 6 * t_ * t_ * 64 * 2 + t_ * 384 * 384 * 2 + 2 * t_ * 384 * 1536 * 2) + cells_ * 768 * 384 * 2
+        # the ViT alone, timed on the launch stream with HIP events: its roofline is the dense bf16 MFMA peak
+        tok_buf = pipe_v.tokens_from_images(imgs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nv):
+            pipe_v.tokens_from_images(imgs)
+        e1.record()
+        torch.cuda.synchronize()
+        vit_ms = e0.elapsed_time(e1) / nv
+        del tok_buf
+        vit_tf = n * vit_flop / (vit_ms * 1e-3) / 1e12
         vit_leg = {"value": round(n / dtv, 2), "unit": "frames/s", "ms_per_step": round(dtv * 1e3, 3),
+                   "roofline": {"bound": "mfma", "kernel": "A0 + sslam_vit_forward (61 launches per 64-frame chunk: row-tile GEMMs, attention)",
+                                "achieved": round(vit_tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(vit_tf / 2500.0, 4),
+                                "launch_ms": round(vit_ms, 3), "flop_per_launch": int(n * vit_flop),
+                                "note": "dense bf16 MFMA peak (spec); a pure bf16 MFMA loop on random data sustains ~1.3-1.5 PFLOP/s on this chip (DVFS)"},
                    "what": "images -> A0 -> HIP ViT-S/16 (A1, bf16 MFMA, random DINOv3-architecture weights) -> A2..A9 -> M1",
                    "vit_gflop_per_frame": round(vit_flop / 1e9, 2), "matches_per_pair": round(float(ov["match_count"].float().mean().item()), 1)}
-        del pipe_v, ov
+        del ov
+
+    # additional block (N = 1): single-frame latency, the shape every reference caller has (tools/bench_latency.py)
+    latency = None
+    if world == 1 and not args.no_vit:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_latency
+        latency = bench_latency.measure(pipe_v, toks[:8], imgs[:8], vit_pipe=pipe_v, reps=50)
+        del pipe_v
 
     # additional leg (N = 1): BASELINE configs[1] "bf16 conv stack + fp32 matcher" - the same pass with the saliency CNN and
     # the descriptor MLP on bf16 MFMA.  Not index-exact, so it is never `value`: reported with its agreement rates against
@@ -283,21 +312,26 @@ def main():
         del pipe_b, ob
 
     if rank == 0:
-        stage_ms = {k: round(float(np.mean([a.elapsed_time(b) for a, b in v])), 4) for k, v in ev.items()}
+        # per step: a sharded step extracts in two launch groups (boundary frames first), so sum the launches of a stage
+        stage_ms = {k: round(float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps, 4) for k, v in ev.items()}
         cells = grid * grid
         conv_flop = n * cells * pipe.selector.hidden * (9 * 384) * 2 + n * cells * pipe.selector.hidden * 2
         conv_s = stage_ms["A3_selector_saliency"] * 1e-3
         achieved = conv_flop / conv_s / 1e12
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (FETCH_SIZE / WRITE_SIZE with
         # the gfx950 corrections of MI355X_MICROARCH.md, tools/pmc_summary.py); the committed summary is keyed by workload
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        traffic = traffic_src = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc) and args.workload == "fr1_desk_613" and not args.frames:
             try:
                 k = [v for name, v in json.load(open(pmc)).items() if name.startswith("selector_saliency")][0]
                 traffic = int(k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"])
+                traffic_src = ("NOT measured in this run: from the committed rocprofv3 --pmc summary profiles/" + os.path.basename(pmc) +
+                               " (FETCH_SIZE / WRITE_SIZE passes of the same command, gfx950 corrections applied)")
             except Exception:
-                traffic = None
+                traffic = traffic_src = None
         # parity spot-check against the oracle on the first frames (outside the timed region)
         from oracle import ora
         nchk = min(3, n)
@@ -317,7 +351,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "selector_saliency_kernel (A3 conv3x3 implicit GEMM, fp32 MFMA)",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": n * cells * 384 * 4 + n * cells * 4 + 9 * 384 * pipe.selector.hidden * 4,
                          "flop_per_launch": conv_flop, "launch_ms": stage_ms["A3_selector_saliency"],
                          # context: what the matrix pipe itself sustains on this box (power / clock limited), and the kernel against it
@@ -331,11 +365,18 @@ def main():
         }
         if world == 1 and not args.no_vit:
             res["with_vit"] = vit_leg
+        if latency is not None:
+            res["latency"] = latency
         if bf16_leg is not None:
             res["bf16_mode"] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
+        if not ok:
+            # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
+            res["value_unverified"], res["value"] = res["value"], None
         print(json.dumps(res))
+        if not ok:
+            sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
 

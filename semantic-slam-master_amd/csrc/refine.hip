@@ -206,6 +206,9 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
 
     // ---- phase 0: fill the activation tile (gathered features, or rows of x_in) --------------------------------
     {
+        // thread (row, part) moves the 8-channel chunks j*8 + part, j = 0..5: the 8 lanes of a row cover 64 CONTIGUOUS floats
+        // per step - full 256-byte runs of every tap row, and 8 distinct 4-bank groups for the two ds_write_b128 (the earlier
+        // part*6 + j order put the 8 lanes 48 floats apart: 4-way bank conflicts, PMC SQ_LDS_BANK_CONFLICT)
         const int row = tid >> 3, part = tid & 7;
         long long R = R0 + row;
         if (R > rows - 1) R = rows - 1;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
             const Taps t = make_taps(feat + f * G * G * SSLAM_C, G, kp_xy[2 * R], kp_xy[2 * R + 1]);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const int c0 = 8 * (part * 6 + j);
+                const int c0 = 8 * (j * 8 + part);
                 float4 ev, od;
                 kp8_split(blend4(t, c0), blend4(t, c0 + 4), ev, od);
                 *reinterpret_cast<float4 *>(dst + c0) = ev;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
             const float *src = x_in + R * SSLAM_C;
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const int c0 = 8 * (part * 6 + j);
+                const int c0 = 8 * (j * 8 + part);
                 float4 ev, od;
                 kp8_split(*reinterpret_cast<const float4 *>(src + c0), *reinterpret_cast<const float4 *>(src + c0 + 4), ev, od);
                 *reinterpret_cast<float4 *>(dst + c0) = ev;

@@ -27,7 +27,7 @@ constexpr int LDT = BK + 4;  // padded LDS row (floats): 144 B = 9 x 16 B -> con
 constexpr int NCHUNK = SSLAM_C / BK;
 constexpr int NSTAGE = 9 * NCHUNK;
 
-template <int WM, int WN, int NI, bool BDIRECT>
+template <int WM, int WN, int NI, bool BDIRECT, int MI = 2>
 __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_saliency_kernel(const float *__restrict__ feat, int n_rows, int G,
                                                                  const float *__restrict__ w1p,
                                                                  const float *__restrict__ b1,
@@ -35,13 +35,17 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
                                                                  const float *__restrict__ b2, float *__restrict__ sal,
                                                                  int n_tiles) {
     static_assert(WM * WN == 8, "8 waves");
-    constexpr int BM = 64 * WM;
+    static_assert(MI == 2 || (MI == 1 && NI == 1 && BDIRECT), "latency form: one 32 x 32 tile per wave");
+    constexpr int BM = 32 * MI * WM;        // MI = 1: the LATENCY form - 32-row workgroups, one MFMA tile per wave, so a stage is
+                                            // 16 MFMAs per wave instead of 64 and a frame spreads over 4x as many CUs (25 workgroups
+                                            // at G = 28): the 108-stage k chain is the same single fma chain per output (bit-exact)
     constexpr int HS = 32 * NI * WN;
     constexpr int NSLAB = HS / 64;
-    constexpr int A_ITEMS = BM * 4 / 512;            // 8-float items per thread per stage
+    constexpr int A_ITEMS = BM * 4 >= 512 ? BM * 4 / 512 : 1;   // 8-float items per thread per stage
+    constexpr bool A_PART = BM * 4 < 512;           // fewer items than threads: only the first BM * 4 threads stage A
     constexpr int B_ITEMS = BDIRECT ? 1 : HS * 8 / 512;   // float4 items per thread per stage
     constexpr int STAGE_FLOATS = (BM + (BDIRECT ? 0 : HS)) * LDT;
-    constexpr int RED_FLOATS = NSLAB * BM;
+    constexpr int RED_FLOATS = NSLAB * BM + (MI == 1 ? 4 * 32 * 64 : 0);   // + the odd column waves' products (latency form)
     constexpr int SMEM_FLOATS = 2 * STAGE_FLOATS > RED_FLOATS ? 2 * STAGE_FLOATS : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     int a_row[A_ITEMS], a_kq[A_ITEMS], a_voff[A_ITEMS], a_mask[A_ITEMS];
 #pragma unroll
     for (int i = 0; i < A_ITEMS; i++) {
-        const int it = tid + 512 * i;
+        const int it = A_PART ? (tid < BM * 4 ? tid : 0) : tid + 512 * i;
         a_row[i] = it >> 2;
         a_kq[i] = it & 3;
         const long long m = m0 + a_row[i];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     {                                                                                                              \
         float *As_ = smem + (BUF) * STAGE_FLOATS;                                                                  \
         float *Bs_ = As_ + BM * LDT;                                                                               \
-        _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) {                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_ITEMS; i++) if (!A_PART || tid < BM * 4) {                         \
             float4 ev, od;                                                                                         \
             const bool k_ = ra_ok[i];                                                                              \
             const float4 lo_ = make_float4(k_ ? ra_lo[i].x : 0.f, k_ ? ra_lo[i].y : 0.f, k_ ? ra_lo[i].z : 0.f, k_ ? ra_lo[i].w : 0.f); \
@@ -135,12 +139,12 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     }
 
     // accumulators start from the conv bias: the fma chain is b1[n] + sum_k a_k * w_k in canonical k order
-    f32x16 acc[2][NI];
+    f32x16 acc[MI][NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
         const float bv = b1[wn * 32 * NI + ni * 32 + r];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
     }
@@ -165,13 +169,13 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     __syncthreads();
     for (int s = 0; s < NSTAGE; s++) {
         if (s + 1 < NSTAGE) LOAD_STAGE(s + 1);
-        const float *As = smem + (s & 1) * STAGE_FLOATS + (wm * 64 + r) * LDT + 4 * h;
+        const float *As = smem + (s & 1) * STAGE_FLOATS + (wm * 32 * MI + r) * LDT + 4 * h;
         const float *Bs = smem + (s & 1) * STAGE_FLOATS + BM * LDT + (wn * 32 * NI + r) * LDT + 4 * h;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(As + 8 * g);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(As + 32 * LDT + 8 * g);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(As + (MI == 2 ? 32 : 0) * LDT + 8 * g);
             f32x4 b[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) {
                     acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
-                    acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
+                    if (MI == 2) acc[MI - 1][ni] = mfma32(a1[st], b[ni][st], acc[MI - 1][ni]);
                 }
             // slots are refilled in place with the k-groups of the NEXT stage once their MFMAs have been issued: the first
             // half of the ring in the middle of the stage (pinned there), the second half at its end
@@ -203,20 +207,46 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
     // epilogue: ReLU, 1x1 conv (canonical tree: in-lane pair per 64-column slab, 32-lane butterfly, slabs in
     // order), sigmoid
     float *red = smem;  // [NSLAB][BM]; every wave is past its last LDS read (barrier above)
+    if (MI == 2) {
 #pragma unroll
-    for (int sl = 0; sl < NI / 2; sl++) {
-        const int slab = wn * (NI / 2) + sl;
-        const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
+        for (int sl = 0; sl < NI / 2; sl++) {
+            const int slab = wn * (NI / 2) + sl;
+            const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
+                    const float h1 = acc[mi][(NI > 1 ? 2 * sl + 1 : 0)][e] > 0.0f ? acc[mi][(NI > 1 ? 2 * sl + 1 : 0)][e] : 0.0f;
+                    const float q = h0 * w2a + h1 * w2b;
+                    const float t = bfly32(q);
+                    if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+                }
+        }
+    } else {
+        // latency form: the two 32-column halves of a 64-column slab belong to waves wn = 2 slab and 2 slab + 1.  The odd wave
+        // hands its products h1 * w2b over through LDS; the even wave forms q = h0 * w2a + h1 * w2b exactly as the in-lane
+        // form does (two roundings of the products, one of the sum) and reduces it with the same butterfly.
+        float *xch = smem + NSLAB * BM;           // [4 slabs][16 e][64 lanes]
+        const int slab = wn >> 1;
+        const float w2v = w2[wn * 32 + r];
+        if (wn & 1) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
-                const float h1 = acc[mi][2 * sl + 1][e] > 0.0f ? acc[mi][2 * sl + 1][e] : 0.0f;
-                const float q = h0 * w2a + h1 * w2b;
-                const float t = bfly32(q);
-                if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+                const float h1 = acc[0][0][e] > 0.0f ? acc[0][0][e] : 0.0f;
+                xch[(slab * 16 + e) * 64 + lane] = h1 * w2v;
             }
+        }
+        __syncthreads();
+        if (!(wn & 1)) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[0][0][e] > 0.0f ? acc[0][0][e] : 0.0f;
+                const float q = h0 * w2v + xch[(slab * 16 + e) * 64 + lane];
+                const float t = bfly32(q);
+                if (r == 0) red[slab * BM + crow(e, h)] = t;
+            }
+        }
     }
     __syncthreads();
     for (int t = tid; t < BM; t += 512) {
@@ -232,12 +262,12 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 #undef LOAD_STAGE
 #undef STORE_STAGE
 
-template <int WM, int WN, int NI, bool BD>
+template <int WM, int WN, int NI, bool BD, int MI = 2>
 void launch(const float *feat, long long rows, int G, const float *w1p, const float *b1, const float *w2, const float *b2,
             float *sal, hipStream_t st) {
-    constexpr int BM = 64 * WM;
+    constexpr int BM = 32 * MI * WM;
     const int n_tiles = (int)((rows + BM - 1) / BM);
-    hipLaunchKernelGGL((selector_saliency_kernel<WM, WN, NI, BD>), dim3(n_tiles), dim3(512), 0, st, feat, (int)rows, G, w1p, b1,
+    hipLaunchKernelGGL((selector_saliency_kernel<WM, WN, NI, BD, MI>), dim3(n_tiles), dim3(512), 0, st, feat, (int)rows, G, w1p, b1,
                        w2, b2, sal, n_tiles);
 }
 
@@ -252,7 +282,14 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     hipStream_t st = (hipStream_t)stream;
     // tuning knob; measured on MI355X (613 frames, G=28): 0: 7.16 ms, 1: 7.06, 2: 6.67 (default), 3: 7.97
     static const int variant = getenv("SSLAM_CONV_VARIANT") ? atoi(getenv("SSLAM_CONV_VARIANT")) : 2;
-    if (hs == 256) {
+    // few frames (the drop-in scripts call frame by frame): 128-row tiles would occupy rows / 128 of the 256 CUs for 108
+    // serial stages of 64 MFMAs; the latency form cuts a stage to 16 MFMAs per wave and uses 4x the workgroups (0.12 vs
+    // 0.47 ms for one frame; still ahead at 256 frames: 2.90 vs 3.02 ms)
+    const char *lat_env = getenv("SSLAM_CONV_LATENCY_ROWS");          // 0 forces the throughput form (tests, A/B timing)
+    const long long lat_rows = lat_env ? atoll(lat_env) : 128 * 1800;  // measured cross-over: ~400 frames at G = 28 (6.25 vs 6.10 ms at 613)
+    if (hs == 256 && rows <= lat_rows) {
+        launch<1, 8, 1, true, 1>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
+    } else if (hs == 256) {
         switch (variant) {
             case 0: launch<2, 4, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
             case 1: launch<4, 2, 4, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;

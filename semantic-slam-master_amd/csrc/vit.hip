@@ -881,18 +881,27 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
         g_sslam_launches++;
     }
     const float4 *st4 = (const float4 *)stats;
+    const bool small = (rows + RT_BM - 1) / RT_BM * 4 <= 256;     // <= 8 frames at 448 x 448: latency-shaped launches
     int rt_stop = 0;
 #ifdef SSLAM_RT_PROBE
     { const char *e = getenv("SSLAM_RT_STOP"); rt_stop = e ? atoi(e) : 0; }
 #endif
     for (int L = 0; L < VLAYERS; L++) {
         const sslam_vit_layer_t &ly = w->layer[L];
-        launch_rt<1, 3>(ProLN{x, st4, ly.ln1_g, ly.ln1_b, 1e-5f}, (const bf16 *)ly.wqkv, rows, 3 * VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T, G}, st);
+        // few frames: one 192-column tile per workgroup (6 / 8 column parts instead of 2), so that a frame's 7 row tiles
+        // spread over 42 / 56 CUs and a workgroup's serial chain is 6 groups instead of 18 / 24
+        if (small)
+            launch_rt<1, 1>(ProLN{x, st4, ly.ln1_g, ly.ln1_b, 1e-5f}, (const bf16 *)ly.wqkv, rows, 3 * VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T, G}, st);
+        else
+            launch_rt<1, 3>(ProLN{x, st4, ly.ln1_g, ly.ln1_b, 1e-5f}, (const bf16 *)ly.wqkv, rows, 3 * VD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T, G}, st);
         if (rt_stop == 1) break;
         hipLaunchKernelGGL(attn_kernel, dim3((T + AQ - 1) / AQ, VH, n_frames), dim3(256), 0, st, q, k, v, y, T);
         launch_rt<1, 1>(ProBf16{y, VD}, (const bf16 *)ly.wo, rows, VD, EpiResidual{ly.bo, x, stats}, st);
         if (rt_stop == 2) break;
-        launch_rt<1, 4>(ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wup, rows, VMLP, EpiGelu{ly.bup, hbuf, VMLP}, st);
+        if (small)
+            launch_rt<1, 1>(ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wup, rows, VMLP, EpiGelu{ly.bup, hbuf, VMLP}, st);
+        else
+            launch_rt<1, 4>(ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wup, rows, VMLP, EpiGelu{ly.bup, hbuf, VMLP}, st);
         if (rt_stop == 3) break;
         launch_rt<4, 1>(ProBf16{hbuf, VMLP}, (const bf16 *)ly.wdown, rows, VD, EpiResidual{ly.bdown, x, stats}, st);
         if (rt_stop == 4) break;

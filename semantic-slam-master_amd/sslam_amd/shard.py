@@ -2,15 +2,21 @@
 is single-process.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  A sequence of
-N frames is cut into contiguous blocks, one per rank.  Extraction is independent per frame (BatchNorm statistics
-are per frame), so the only data that crosses GPUs is what the matcher needs at a block boundary:
+N frames is cut into contiguous blocks, one per rank (`shard_bounds`).  Extraction is independent per frame (BatchNorm
+statistics are per frame), so the only data that crosses GPUs is what the matcher needs at a block boundary and the
+results:
 
-  1. halo - each rank sends the descriptors / scores / intensities of its FIRST `spacing` frames to rank-1
-     (point-to-point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link, never bandwidth-bound);
-  2. results - per-rank pair counts are all-gathered, then the padded match records are all-gathered and kept by
-     rank 0 (all_gather rather than gather: fixed-size, the most widely exercised RCCL collective).
+  1. halo - each rank sends the descriptors / scores / intensities of its FIRST `spacing` frames to rank-1 (point to
+     point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link).  Those frames are extracted FIRST, as their
+     own small launch group, and the isend / irecv are posted before the rest of the block is extracted - the transfer
+     overlaps the bulk of the extraction;
+  2. results - rank 0 alone receives the matches, COMPACTED on the sending GPU: one int32 record (global pair index,
+     idx1, idx2, quality bits) per match, 16 bytes (the padded (pairs, K, 2) int64 + (pairs, K) fp32 arrays are 20 bytes per
+     SLOT: 10 KB per pair at K = 500 whatever the match count).  Sizes are exchanged once per run (one 16-byte all-gather
+     and the only host synchronisation of the step, after everything else has been enqueued), then every rank r > 0 does
+     one send and rank 0 one recv per rank into its slice of the result.
 
-No all-reduce, no weight traffic after the optional initial broadcast of the packed weights.
+No all-reduce, no all-gather of payload, no weight traffic after the optional initial broadcast of the packed weights.
 """
 from __future__ import annotations
 
@@ -33,10 +39,47 @@ def broadcast_weights(tensors: list, src: int = 0):
         dist.broadcast(t, src=src)
 
 
+def compact_records(matches: torch.Tensor, quality: torch.Tensor, match_count: torch.Tensor, first_pair: int):
+    """(p, K, 2) int64 / (p, K) fp32 / (p,) counts -> ((p*K, 4) int32 buffer, device scalar M): rows 0..M-1 are (global pair
+    index, idx1, idx2, quality bits), pairs ascending and idx1 ascending inside a pair - exactly the valid slots, in order.
+    Prefix-sum + scatter on the device: no host synchronisation (boolean-mask indexing would need one)."""
+    p, K = quality.shape
+    dev = quality.device
+    buf = torch.zeros((p * K + 1, 4), dtype=torch.int32, device=dev)          # last row: dump slot for the padding
+    if p == 0:
+        return buf[:0], torch.zeros((), dtype=torch.int64, device=dev)
+    cnt = match_count.to(torch.int64)
+    start = torch.cumsum(cnt, 0) - cnt
+    slot = torch.arange(K, device=dev)
+    keep = slot[None, :] < cnt[:, None]
+    dst = torch.where(keep, start[:, None] + slot[None, :], torch.full((), p * K, dtype=torch.int64, device=dev))
+    pair = (torch.arange(p, device=dev, dtype=torch.int32) + first_pair)[:, None].expand(p, K)
+    rec = torch.stack([pair, matches[..., 0].to(torch.int32), matches[..., 1].to(torch.int32), quality.view(torch.int32)], dim=-1)
+    buf[dst.reshape(-1)] = rec.reshape(-1, 4)
+    return buf[: p * K], cnt.sum()
+
+
+def expand_records(rec: torch.Tensor, n_pairs: int, K: int) -> dict:
+    """Inverse of compact_records on the receiving side: the padded arrays of a single-process run."""
+    dev = rec.device
+    matches = torch.zeros((n_pairs, K, 2), dtype=torch.int64, device=dev)
+    quality = torch.zeros((n_pairs, K), dtype=torch.float32, device=dev)
+    pair = rec[:, 0].long()
+    count = torch.bincount(pair, minlength=n_pairs).to(torch.int32)
+    start = torch.cumsum(count, 0) - count
+    slot = torch.arange(rec.shape[0], device=dev) - start[pair]
+    matches[pair, slot, 0] = rec[:, 1].long()
+    matches[pair, slot, 1] = rec[:, 2].long()
+    quality[pair, slot] = rec[:, 3].contiguous().view(torch.float32)
+    return dict(all_matches=matches, all_quality=quality, all_match_count=count)
+
+
 class ShardedSequenceRunner:
     """extract_fn(tokens, images) -> dict with 'descriptors' (n, K, D), 'scores' (n, K), optional 'intensity' (n, K)
     match_fn(desc, scores, intensity, spacing) -> dict with 'matches' (p, K, 2) int64, 'quality' (p, K), 'match_count' (p,)
-    Both run on this rank's device; in production they are SequencePipeline.extract / .match."""
+    Both run on this rank's device; in production they are SequencePipeline.extract / .match.
+    `first_frame` = global index of this rank's first frame (shard_bounds(...)[0]); it turns local pair numbers into the
+    sequence's pair numbers in the gathered records."""
 
     def __init__(self, extract_fn: Callable, match_fn: Callable, spacing: int = 1, group=None):
         self.extract_fn, self.match_fn, self.spacing, self.group = extract_fn, match_fn, spacing, group
@@ -44,13 +87,11 @@ class ShardedSequenceRunner:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     # ------------------------------------------------------------------------------------------------ halo
-    def _exchange_halo(self, fields: dict) -> dict:
-        """Send my first `spacing` frames to rank-1, receive rank+1's.  Returns the received tensors ({} on the last rank)."""
+    def _post_halo(self, head: dict):
+        """Post the sends of my first `spacing` frames to rank-1 and the receives from rank+1; returns (requests, recv)."""
         sp, r, w = self.spacing, self.rank, self.world
-        if w == 1:
-            return {}
         ops, recv = [], {}
-        for name, t in fields.items():
+        for name, t in head.items():
             if t is None:
                 continue
             if r > 0:
@@ -58,58 +99,66 @@ class ShardedSequenceRunner:
             if r < w - 1:
                 recv[name] = torch.empty((sp,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
                 ops.append(dist.P2POp(dist.irecv, recv[name], r + 1, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return recv
+        return (dist.batch_isend_irecv(ops) if ops else []), recv
 
     # ------------------------------------------------------------------------------------------------- run
-    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True) -> dict:
+    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True, first_frame: int = 0) -> dict:
         """Processes this rank's block.  Every rank must hold at least `spacing` frames."""
-        sp = self.spacing
-        assert tokens_local.shape[0] >= sp, "each shard needs at least `spacing` frames"
-        ex = self.extract_fn(tokens_local, images_local)
-        fields = dict(descriptors=ex["descriptors"], scores=ex["scores"], intensity=ex.get("intensity"))
-        halo = self._exchange_halo(fields)
-        if halo:
-            desc = torch.cat([fields["descriptors"], halo["descriptors"]])
-            sc = torch.cat([fields["scores"], halo["scores"]])
-            inten = None if fields["intensity"] is None else torch.cat([fields["intensity"], halo["intensity"]])
+        sp, n = self.spacing, tokens_local.shape[0]
+        assert n >= sp, "each shard needs at least `spacing` frames"
+        names = ("descriptors", "scores", "intensity")
+        reqs, halo = [], {}
+        if self.world > 1 and n > sp:
+            # boundary frames first: their descriptors travel while the rest of the block is being extracted
+            ex_head = self.extract_fn(tokens_local[:sp], None if images_local is None else images_local[:sp])
+            reqs, halo = self._post_halo({k: ex_head.get(k) for k in names})
+            ex_tail = self.extract_fn(tokens_local[sp:], None if images_local is None else images_local[sp:])
+            ex = {k: torch.cat([ex_head[k], ex_tail[k]]) for k in ex_head}
         else:
-            desc, sc, inten = fields["descriptors"], fields["scores"], fields["intensity"]
-        m = self.match_fn(desc, sc, inten, sp)          # pairs (i, i+sp) for every local i that has a partner
+            ex = self.extract_fn(tokens_local, images_local)
+            if self.world > 1:
+                reqs, halo = self._post_halo({k: ex.get(k) for k in names})
+        for req in reqs:
+            req.wait()
+        fields = {k: ex.get(k) for k in names}
+        if halo:
+            fields = {k: (None if v is None else torch.cat([v, halo[k]])) for k, v in fields.items()}
+        m = self.match_fn(fields["descriptors"], fields["scores"], fields["intensity"], sp)   # every local i that has a partner
         out = dict(ex)
         out.update(m)
         out["n_local_pairs"] = int(m["match_count"].shape[0])
         if gather_results and self.world > 1:
-            out.update(self._gather(m))
+            out.update(self._gather(m, first_frame))
         return out
 
     # ---------------------------------------------------------------------------------------------- gather
-    def _gather(self, m: dict) -> dict:
-        """All ranks learn every rank's pair count, then the padded match records are all-gathered (one fixed-size
-        collective per array; <= 10 KB per pair) and rank 0 keeps them, concatenated in frame order."""
+    def _gather(self, m: dict, first_frame: int) -> dict:
+        """Compacted match records -> rank 0 (module docstring, item 2).  Rank 0 returns the padded arrays of the whole
+        sequence ('all_matches', 'all_quality', 'all_match_count') and the raw records; other ranks only the sizes."""
         w, r = self.world, self.rank
-        dev = m["match_count"].device
-        npairs = torch.tensor([m["match_count"].shape[0]], dtype=torch.int64, device=dev)
-        all_np = [torch.zeros_like(npairs) for _ in range(w)]
-        dist.all_gather(all_np, npairs, group=self.group)
-        counts = [int(x.item()) for x in all_np]
-        pmax = max(counts)
+        rec, n_valid = compact_records(m["matches"], m["quality"], m["match_count"], first_frame)
+        dev = rec.device
+        sizes = torch.stack([torch.tensor(m["match_count"].shape[0], dtype=torch.int64, device=dev), n_valid])
+        all_sizes = [torch.zeros_like(sizes) for _ in range(w)]
+        dist.all_gather(all_sizes, sizes, group=self.group)
+        table = torch.stack(all_sizes).tolist()       # the step's one host synchronisation: [[pairs, records], ...] per rank
+        pairs = [int(t[0]) for t in table]
+        nrec = [int(t[1]) for t in table]
+        res = {"pairs_per_rank": pairs, "records_per_rank": nrec}
         K = m["matches"].shape[1]
-
-        def pad(t, shape, dtype):
-            buf = torch.zeros((pmax,) + shape, dtype=dtype, device=dev)
-            buf[: t.shape[0]] = t
-            return buf
-
-        send = [pad(m["match_count"], (), torch.int32), pad(m["quality"], (K,), torch.float32),
-                pad(m["matches"], (K, 2), torch.int64)]
-        res = {}
-        for name, t in zip(("all_match_count", "all_quality", "all_matches"), send):
-            bufs = [torch.empty_like(t) for _ in range(w)]
-            dist.all_gather(bufs, t, group=self.group)
-            if r == 0:
-                res[name] = torch.cat([b[:c] for b, c in zip(bufs, counts)])
-        res["pairs_per_rank"] = counts
+        if r == 0:
+            buf = torch.empty((sum(nrec), 4), dtype=torch.int32, device=dev)
+            buf[: nrec[0]] = rec[: nrec[0]]
+            ops, off = [], nrec[0]
+            for src in range(1, w):
+                if nrec[src]:
+                    ops.append(dist.P2POp(dist.irecv, buf[off:off + nrec[src]], src, self.group))
+                off += nrec[src]
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            res["records"] = buf
+            res.update(expand_records(buf, sum(pairs), K))
+        elif nrec[r]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec[: nrec[r]].contiguous(), 0, self.group)]):
+                req.wait()
         return res

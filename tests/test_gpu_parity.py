@@ -91,8 +91,11 @@ def _packed_selector(T, hip, sd):
             sd["conv.0.weight"].shape[0])
 
 
+@pytest.mark.parametrize("form", ["latency", "throughput"])
 @pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (60, 1, 256), (28, 2, 128), (5, 2, 256)])
-def test_selector_saliency(T, hip, grid, frames, hidden):
+def test_selector_saliency(T, hip, grid, frames, hidden, form, monkeypatch):
+    """Both launch shapes of the conv: 32-row workgroups (few frames: the default below 24 576 cells) and 128-row ones."""
+    monkeypatch.setenv("SSLAM_CONV_LATENCY_ROWS", "0" if form == "throughput" else str(1 << 30))
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
     feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
     w1p, b1, w2, b2, hs = _packed_selector(T, hip, sd)

@@ -1,5 +1,6 @@
 """CPU test of the frame-sharded N > 1 path (sslam_amd/shard.py) with torch.distributed on the gloo backend,
-world_size 2 and 3: block partition, halo exchange of boundary-frame descriptors, gather of match records to rank 0.
+world_size 2, 3 and 4: block partition, early halo exchange of boundary-frame descriptors (boundary frames extracted as
+their own launch group), gather of COMPACTED match records to rank 0 only.
 The compute functions are injected (here: the CPU oracle on small inputs; in production the HIP pipeline), so the
 test checks exactly the distributed logic: the sharded result must equal the single-process result pair for pair."""
 import os
@@ -69,17 +70,26 @@ def _worker(rank, world, port, n_frames, spacing, q):
         w = torch.full((7,), float(rank))
         broadcast_weights([w], src=0)
         assert float(w.sum()) == 0.0
-        runner = ShardedSequenceRunner(_extract, _match, spacing=spacing)
-        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]))
+        calls = []
+
+        def extract(tokens, images):
+            calls.append(tokens.shape[0])
+            return _extract(tokens, images)
+
+        runner = ShardedSequenceRunner(extract, _match, spacing=spacing)
+        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), first_frame=lo)
+        # the boundary frames go first, as their own group, whenever the block is longer than the halo
+        assert calls == ([spacing, hi - lo - spacing] if hi - lo > spacing else [hi - lo]), calls
         if rank == 0:
-            q.put((out["all_match_count"].numpy(), out["all_matches"].numpy(), out["all_quality"].numpy(), out["pairs_per_rank"]))
+            q.put((out["all_match_count"].numpy(), out["all_matches"].numpy(), out["all_quality"].numpy(), out["pairs_per_rank"],
+                   out["records"].numpy(), out["records_per_rank"]))
         else:
-            assert "all_matches" not in out
+            assert "all_matches" not in out and "records" not in out      # payload goes to rank 0 only
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,spacing", [(2, 9, 1), (3, 11, 2), (2, 4, 2)])
+@pytest.mark.parametrize("world,n_frames,spacing", [(2, 9, 1), (3, 11, 2), (2, 4, 2), (4, 14, 1)])
 def test_sharded_equals_single_process(world, n_frames, spacing):
     from sslam_amd.shard import shard_bounds
     # partition covers every frame exactly once, contiguously
@@ -91,7 +101,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q)) for r in range(world)]
     for p in procs:
         p.start()
-    cnt, mt, qual, per_rank = q.get(timeout=120)
+    cnt, mt, qual, per_rank, records, rec_per_rank = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -102,3 +112,9 @@ def test_sharded_equals_single_process(world, n_frames, spacing):
     assert np.array_equal(mt, ref["matches"].numpy())
     assert np.array_equal(qual.view(np.uint32), ref["quality"].numpy().view(np.uint32))
     assert cnt.sum() > 0
+    # the wire format: one 16-byte record per match, pairs ascending, idx1 ascending inside a pair - nothing padded travels
+    assert records.shape == (int(cnt.sum()), 4) and records.dtype == np.int32 and sum(rec_per_rank) == records.shape[0]
+    assert np.array_equal(records[:, 0], np.repeat(np.arange(n_frames - spacing), cnt))
+    want = np.concatenate([ref["matches"].numpy()[i, :c] for i, c in enumerate(cnt)])
+    assert np.array_equal(records[:, 1:3], want)
+    assert records.nbytes == 16 * int(cnt.sum()) < mt.nbytes + qual.nbytes      # padded arrays: 20 bytes per SLOT
