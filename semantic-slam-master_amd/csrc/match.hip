@@ -11,14 +11,22 @@
 // The MFMA tile is oriented with the QUERY on the lane (B operand) and the candidates on the accumulator rows
 // (A operand): each lane then owns one query and scans its 16 candidate rows per tile in increasing index with a
 // strict '>' - a register-local arg-max that keeps the first maximum (torch / numpy semantics); only
-// the two half-waves and the two candidate waves are merged at the end (value, then lower index).
+// the two half-waves are merged at the end (value, then lower index).
+// A workgroup is 4 waves = 128 queries; every wave keeps ITS 32 queries in registers for the whole kernel (the B operand
+// of v_mfma_f32_32x32x2_f32 is one VGPR per k pair: 64 VGPRs for d = 128), so LDS holds only the double-buffered
+// candidate tiles (2 x 33 KB) and TWO workgroups share a CU.  That is the point: the reduction of a stage (row scan +
+// the 64-bit key butterfly of the single-evaluation form, ~1 100 vector instructions per wave) follows its 128 MFMAs in
+// every wave of a workgroup at the same time - with one workgroup per CU the matrix pipe idled through every reduction
+// (measured 0.50 ms, of it 0.09 for the butterfly and 0.14 for the unoverlapped prologue / staging); two independent
+// workgroups drift apart and fill each other's gaps.
 // Roofline: MFMA-bound (2 * n1 * n2 * 128 * 2 FLOP per pair incl. both directions; 128 MFLOP at 500 keypoints).
 #include "common.h"
 
 namespace {
 
-constexpr int QB = 128;            // queries per workgroup
-constexpr int CB = 64;             // candidates per stage
+constexpr int QB = 128;            // queries per workgroup (32 per wave)
+constexpr int CB = 64;             // candidates per stage (two MFMA tiles per wave)
+constexpr int NTM = 256;           // threads per workgroup
 constexpr int LDD = SSLAM_D + 4;   // 132-float rows: 528 B = 33 x 16 B -> conflict-free b128 fragment reads
 
 // rows x 128 floats -> KP8 image, split into a load half (global -> registers) and a store half (registers -> LDS)
@@ -26,13 +34,13 @@ constexpr int LDD = SSLAM_D + 4;   // 132-float rows: 528 B = 33 x 16 B -> confl
 // rows beyond n_valid are zero (they are masked out of the arg-max anyway)
 template <int ROWS>
 struct Stager {
-    static constexpr int ITEMS = ROWS * 16 / 512;
+    static constexpr int ITEMS = ROWS * 16 / NTM;
     float4 lo[ITEMS], hi[ITEMS];
     bool ok[ITEMS];         // rows beyond n_valid are zeroed at store time: nothing waits for the loads before the MFMAs
     __device__ __forceinline__ void load(const float *__restrict__ src, int first, int n_valid, int tid) {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const int it = tid + 512 * i, row = it >> 4, g = it & 15;
+            const int it = tid + NTM * i, row = it >> 4, g = it & 15;
             ok[i] = first + row < n_valid;
             const float4 *p = reinterpret_cast<const float4 *>(src + (long long)(ok[i] ? first + row : 0) * SSLAM_D + 8 * g);
             lo[i] = p[0];
@@ -42,7 +50,7 @@ struct Stager {
     __device__ __forceinline__ void store(float *dst, int tid) const {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const int it = tid + 512 * i, row = it >> 4, g = it & 15;
+            const int it = tid + NTM * i, row = it >> 4, g = it & 15;
             float4 ev, od;
             const bool k = ok[i];
             kp8_split(make_float4(k ? lo[i].x : 0.f, k ? lo[i].y : 0.f, k ? lo[i].z : 0.f, k ? lo[i].w : 0.f),
@@ -61,22 +69,77 @@ __device__ __forceinline__ unsigned long long sim_key(float v, int i) {
     return ((unsigned long long)u << 32) | (unsigned)(~i);
 }
 
+// The reduction of one finished 32 x 32 tile, cut into 24 micro-steps so that the kernel can issue a few of them behind
+// every group of MFMAs of the NEXT stage (software pipelining by hand; the scheduler left alone puts all MFMAs first):
+//   0..7    row scan of accumulator rows 2 STEP, 2 STEP + 1: register-local first-max (+ runner-up) per query lane
+//   8..15   column butterfly, xor 16: builds the 64-bit keys of rows i, i + 8 and keeps one of them (reduce-scatter)
+//   16..19  xor 8 (4 exchanges), 20..21 xor 4, 22 xor 2, 23 xor 1 -> kk = key of accumulator row crow((r >> 1) & 15, h)
+struct RowBest {
+    float best, second;
+    int besti;
+};
+template <int STEP, bool ONEPASS>
+__device__ __forceinline__ void red_step(const f32x16 &acc, int jbase, int nc, int r, int h, bool qok, int qi, RowBest &rb,
+                                         unsigned long long (&k)[8], unsigned long long &kk, int &jj) {
+    if constexpr (STEP < 8) {
+#pragma unroll
+        for (int e = 2 * STEP; e < 2 * STEP + 2; e++) {   // branch-free form of: if (v > best) {second = best; best = v; besti = j;}
+            const int j = jbase + crow(e, h);             //                  else if (v > second) second = v;      (rows j >= nc skipped)
+            const float v = j < nc ? acc[e] : -INFINITY;
+            const bool gt = v > rb.best;
+            rb.second = gt ? rb.best : fmaxf(rb.second, v);
+            rb.besti = gt ? j : rb.besti;
+            rb.best = gt ? v : rb.best;
+        }
+    } else if constexpr (!ONEPASS) {
+    } else if constexpr (STEP < 16) {
+        constexpr int i = STEP - 8;
+        const bool up = (r & 16) != 0;
+        unsigned long long lo = qok ? sim_key(acc[i], qi) : 0ull, hi = qok ? sim_key(acc[i + 8], qi) : 0ull;
+        asm("" : "+v"(lo), "+v"(hi));          // keeps the selects from being folded into a dynamic vector index
+        const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
+        const unsigned long long o = __shfl_xor(send, 16);
+        k[i] = keep > o ? keep : o;
+    } else if constexpr (STEP < 23) {
+        constexpr int m = STEP < 20 ? 4 : (STEP < 22 ? 2 : 1);
+        constexpr int i = STEP < 20 ? STEP - 16 : (STEP < 22 ? STEP - 20 : 0);
+        const bool up = (r & (2 * m)) != 0;
+        unsigned long long lo = k[i], hi = k[i + m];
+        asm("" : "+v"(lo), "+v"(hi));
+        const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
+        const unsigned long long o = __shfl_xor(send, 2 * m);
+        k[i] = keep > o ? keep : o;
+    } else {
+        const unsigned long long o = __shfl_xor(k[0], 1);
+        kk = k[0] > o ? k[0] : o;
+        jj = jbase + crow((r >> 1) & 15, h);       // the accumulator row this lane pair ended up holding
+    }
+}
+// micro-steps [FIRST, FIRST + N) of the 48 of a stage (two tiles)
+template <int FIRST, int N, bool ONEPASS>
+__device__ __forceinline__ void red_steps(const f32x16 (&acc)[2], int s, int nc, int r, int h, bool qok, int qi, RowBest &rb,
+                                          unsigned long long (&k)[2][8], unsigned long long (&kk)[2], int (&jj)[2]) {
+    if constexpr (N > 0) {
+        constexpr int ct = FIRST / 24;
+        red_step<FIRST % 24, ONEPASS>(acc[ct], s * CB + ct * 32, nc, r, h, qok, qi, rb, k[ct], kk[ct], jj[ct]);
+        red_steps<FIRST + 1, N - 1, ONEPASS>(acc, s, nc, r, h, qok, qi, rb, k, kk, jj);
+    }
+}
+
 // ONEPASS = false: grid (query blocks, 2 directions, pairs) - S is evaluated once per direction, nothing but the outputs
 //                  is written (single pairs / small batches: twice the workgroups to spread over the CUs).
 // ONEPASS = true:  grid (query blocks, 1, pairs) - S is evaluated ONCE; the column direction (nn21) is reduced over the
 //                  32 query lanes of each half-wave by a reduce-scatter butterfly on sim_key()s and merged across waves
 //                  and workgroups with a 64-bit atomic max into `keys` (n_pairs x n2, zeroed), decoded by keys_decode_kernel.
 template <bool ONEPASS>
-__global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
-                                                          const float *__restrict__ desc2, long long stride2, int n2,
-                                                          int *__restrict__ nn12, float *__restrict__ s12,
-                                                          int *__restrict__ nn21, float *__restrict__ s21,
-                                                          float *__restrict__ second12,
-                                                          unsigned long long *__restrict__ keys) {
-    __shared__ __attribute__((aligned(16))) float smem[(QB + 2 * CB) * LDD];
-    float *Qs = smem, *Cs = smem + QB * LDD;
+__global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
+                                                            const float *__restrict__ desc2, long long stride2, int n2,
+                                                            int *__restrict__ nn12, float *__restrict__ s12,
+                                                            int *__restrict__ nn21, float *__restrict__ s21,
+                                                            float *__restrict__ second12,
+                                                            unsigned long long *__restrict__ keys) {
+    __shared__ __attribute__((aligned(16))) float Cs[2 * CB * LDD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int wq = wave & 3, wc = wave >> 2;
     const int dir = blockIdx.y;
     const long long pair = blockIdx.z;
     const float *q = dir == 0 ? desc1 + pair * stride1 : desc2 + pair * stride2;
@@ -88,79 +151,102 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
     float *o_val = dir == 0 ? (s12 ? s12 + pair * n1 : nullptr) : (s21 ? s21 + pair * n2 : nullptr);
     float *o_sec = (dir == 0 && second12) ? second12 + pair * n1 : nullptr;
 
-    {
-        Stager<QB> sq;
-        sq.load(q, q0, nq, tid);
-        sq.store(Qs, tid);
-    }
     Stager<CB> sc;
     sc.load(c, 0, nc, tid);
+    // this lane's query as the B operand of all 64 MFMA steps: step i multiplies k = 2 i + h
+    const int qi = q0 + wave * 32 + r;
+    const bool qok = qi < nq;
+    float qreg[SSLAM_D / 2];
+    {
+        // rows beyond nq re-read row 0 and are multiplied by 0 (finite data; exact for the valid rows): a select on qok around
+        // the loads makes hipcc branch around EACH load and wait for it - 32 serial memory round trips in the prologue
+        const float4 *qp = reinterpret_cast<const float4 *>(q + (long long)(qok ? qi : 0) * SSLAM_D);
+        const float qm = qok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < SSLAM_D / 4; i++) {
+            const float4 v = qp[i];
+            qreg[2 * i] = (h ? v.y : v.x) * qm;
+            qreg[2 * i + 1] = (h ? v.w : v.z) * qm;
+        }
+    }
     sc.store(Cs, tid);
     __syncthreads();
 
-    float best = -INFINITY, second = -INFINITY;   // second: best of the row once the winner is removed
-    int besti = 0x7fffffff;
+    RowBest rb = {-INFINITY, -INFINITY, 0x7fffffff};     // second: best of the row once the winner is removed
     const int nstage = (nc + CB - 1) / CB;
-    const float *B = Qs + (wq * 32 + r) * LDD + 4 * h;
-    for (int s = 0; s < nstage; s++) {
-        if (s + 1 < nstage) sc.load(c, (s + 1) * CB, nc, tid);     // in flight during the MFMAs below
-        const float *A = Cs + (s & 1) * CB * LDD + (wc * 32 + r) * LDD + 4 * h;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < SSLAM_D / 8; g++) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(B + 8 * g);
-#pragma unroll
-            for (int st = 0; st < 4; st++) acc = mfma32(a[st], b[st], acc);
-        }
-        const int jbase = s * CB + wc * 32;
-#pragma unroll
-        for (int e = 0; e < 16; e++) {   // branch-free form of: if (v > best) {second = best; best = v; besti = j;}
-            const int j = jbase + crow(e, h);  //                  else if (v > second) second = v;      (rows j >= nc skipped)
-            const float v = j < nc ? acc[e] : -INFINITY;
-            const bool gt = v > best;
-            second = gt ? best : fmaxf(second, v);
-            besti = gt ? j : besti;
-            best = gt ? v : best;
-        }
+
+    // A stage = 128 MFMAs (two 32 x 32 tiles against the wave's queries) + its reduction (row scan; in the single-evaluation
+    // form also the column butterfly on 64-bit keys): ~1 100 vector instructions that depend on the finished tiles.  Run one
+    // after the other, the matrix pipe idles through every reduction - and a second workgroup on the CU does not fill the gap:
+    // two waves sharing a pipe fairly finish their MFMA phases together, so they also reduce together (PMC: pipe 54 % busy,
+    // MFMA + VALU time adding up to the kernel time).  The loop is therefore software-pipelined INSIDE the wave, by hand:
+    // iteration s multiplies stage s and, behind every group of 8 MFMAs (512 cycles of matrix work), issues 3 of the 48
+    // micro-steps that reduce stage s - 1 (held in 32 registers).  sched_barrier pins that order (left alone, hipcc issues
+    // the 128 MFMAs back to back and the reduction after them; sched_group_barrier pipelines were not honoured here).
+#define M1_MMA(g_, A_, acc_)                                                                                          \
+    {                                                                                                                 \
+        /* KP8 image: the float4 at 8 g + 4 h holds k = 8 g + 2 st + h, st = 0..3 -> MFMA step 4 g + st */            \
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>((A_) + 8 * (g_));                                          \
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>((A_) + 32 * LDD + 8 * (g_));                                \
+        _Pragma("unroll") for (int st = 0; st < 4; st++) {                                                            \
+            acc_[0] = mfma32(a0[st], qreg[4 * (g_) + st], acc_[0]);                                                   \
+            acc_[1] = mfma32(a1[st], qreg[4 * (g_) + st], acc_[1]);                                                   \
+        }                                                                                                             \
+    }
+    auto commit = [&](const unsigned long long (&kk)[2], const int (&jj)[2]) {
         if (ONEPASS) {
-            const int qi = q0 + wq * 32 + r;
-            const bool qok = qi < nq;
-            unsigned long long k[8];
-            {
-                const bool up = (r & 16) != 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    unsigned long long lo = qok ? sim_key(acc[i], qi) : 0ull, hi = qok ? sim_key(acc[i + 8], qi) : 0ull;
-                    asm volatile("" : "+v"(lo), "+v"(hi));      // keeps the selects from being folded into a dynamic vector index
-                    const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
-                    const unsigned long long o = __shfl_xor(send, 16);
-                    k[i] = keep > o ? keep : o;
-                }
-            }
-#pragma unroll
-            for (int m = 4; m >= 1; m >>= 1) {
-                const bool up = (r & (2 * m)) != 0;
-#pragma unroll
-                for (int i = 0; i < m; i++) {
-                    unsigned long long lo = k[i], hi = k[i + m];
-                    asm volatile("" : "+v"(lo), "+v"(hi));
-                    const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
-                    const unsigned long long o = __shfl_xor(send, 2 * m);
-                    k[i] = keep > o ? keep : o;
-                }
-            }
-            const unsigned long long o = __shfl_xor(k[0], 1);
-            const unsigned long long kk = k[0] > o ? k[0] : o;
-            const int j = jbase + crow((r >> 1) & 15, h);       // the accumulator row this lane pair ended up holding
-            if (!(r & 1) && j < nc) atomicMax(keys + pair * n2 + j, kk);
+            for (int ct = 0; ct < 2; ct++)
+                if (!(r & 1) && jj[ct] < nc) atomicMax(keys + pair * n2 + jj[ct], kk[ct]);
         }
+    };
+
+    f32x16 held[2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) held[0][e] = held[1][e] = 0.0f;
+    {
+        const float *A = Cs + r * LDD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < SSLAM_D / 8; g++) M1_MMA(g, A, held)
+    }
+    if (nstage > 1) {
+        sc.load(c, CB, nc, tid);
+        sc.store(Cs + CB * LDD, tid);
+    }
+    __syncthreads();
+    unsigned long long kq[2][8];
+    for (int s = 1; s < nstage; s++) {
+        if (s + 1 < nstage) sc.load(c, (s + 1) * CB, nc, tid);     // in flight during the MFMAs below
+        const float *A = Cs + (s & 1) * CB * LDD + r * LDD + 4 * h;
+        f32x16 acc[2];
+        unsigned long long kk[2] = {0ull, 0ull};
+        int jj[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][e] = acc[1][e] = 0.0f;
+#define M1_SLOT(g_)                                                                                                   \
+        M1_MMA(g_, A, acc)                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        red_steps<3 * (g_), 3, ONEPASS>(held, s - 1, nc, r, h, qok, qi, rb, kq, kk, jj);                              \
+        __builtin_amdgcn_sched_barrier(0);
+        M1_SLOT(0) M1_SLOT(1) M1_SLOT(2) M1_SLOT(3) M1_SLOT(4) M1_SLOT(5) M1_SLOT(6) M1_SLOT(7)
+        M1_SLOT(8) M1_SLOT(9) M1_SLOT(10) M1_SLOT(11) M1_SLOT(12) M1_SLOT(13) M1_SLOT(14) M1_SLOT(15)
+#undef M1_SLOT
+        commit(kk, jj);
+        held[0] = acc[0];
+        held[1] = acc[1];
         if (s + 1 < nstage) sc.store(Cs + ((s + 1) & 1) * CB * LDD, tid);
         __syncthreads();
     }
-    // merge the two half-waves (same query, interleaved candidate rows), then the two candidate waves
+#undef M1_MMA
+    {
+        unsigned long long kk[2] = {0ull, 0ull};
+        int jj[2] = {0, 0};
+        red_steps<0, 48, ONEPASS>(held, nstage - 1, nc, r, h, qok, qi, rb, kq, kk, jj);
+        commit(kk, jj);
+    }
+    float best = rb.best, second = rb.second;
+    int besti = rb.besti;
+    // merge the two half-waves (same query, interleaved candidate rows)
     {
         const float ov = __shfl_xor(best, 32), os = __shfl_xor(second, 32);
         const int oi = __shfl_xor(besti, 32);
@@ -172,30 +258,10 @@ __global__ __launch_bounds__(512) void sim_argmax_kernel(const float *__restrict
             second = fmaxf(second, ov);
         }
     }
-    float *mv = smem;                                     // [2][128]
-    int *mi = reinterpret_cast<int *>(smem + 2 * QB);      // [2][128]
-    float *ms = smem + 4 * QB;                             // [2][128]
-    if (h == 0) {
-        mv[wc * QB + wq * 32 + r] = best;
-        mi[wc * QB + wq * 32 + r] = besti;
-        ms[wc * QB + wq * 32 + r] = second;
-    }
-    __syncthreads();
-    if (tid < QB && q0 + tid < nq) {
-        float v = mv[tid], sc = ms[tid];
-        int i = mi[tid];
-        const float v1 = mv[QB + tid], sc1 = ms[QB + tid];
-        const int i1 = mi[QB + tid];
-        if (v1 > v || (v1 == v && i1 < i)) {
-            sc = fmaxf(v, sc1);
-            v = v1;
-            i = i1;
-        } else {
-            sc = fmaxf(sc, v1);
-        }
-        o_idx[q0 + tid] = i;
-        if (o_val) o_val[q0 + tid] = v;
-        if (o_sec) o_sec[q0 + tid] = sc;
+    if (h == 0 && qok) {
+        o_idx[qi] = besti;
+        if (o_val) o_val[qi] = best;
+        if (o_sec) o_sec[qi] = second;
     }
 }
 
@@ -291,7 +357,7 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
             (void)hipFreeAsync(keys, st);
             return SSLAM_E_LAUNCH;
         }
-        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
+        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(NTM), 0, st, desc1, stride1, n1,
                            desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys);
         g_sslam_launches++;
         bool ok = hipGetLastError() == hipSuccess;
@@ -305,7 +371,7 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
         return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
     }
     const int nmax = n1 > n2 ? n1 : n2;
-    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(512), 0, st, desc1, stride1, n1,
+    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(NTM), 0, st, desc1, stride1, n1,
                        desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;

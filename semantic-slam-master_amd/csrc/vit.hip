@@ -156,11 +156,16 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
             rstd[i] = rsqrtf(var + eps);
             xr[i] = x + (long long)row * VD + 4 * p;
         }
-        // six batches of 64 features; batch c + 1 is in flight while batch c is normalised (two register sets, named)
-        f32x4 xa[2][4], xb[2][4];
-#define LN_LOAD(dst, c_)                                                                                             \
-    _Pragma("unroll") for (int hf = 0; hf < 2; hf++) _Pragma("unroll") for (int i = 0; i < 4; i++)                     \
-        rt_gload(dst[hf][i], xr[i] + 64 * (c_) + 32 * hf);
+        // six batches of 64 features (8 x 16 bytes per lane each).  ALL 48 loads are requested up front - 192 registers, free at
+        // this point: no accumulator is live and the fragments are produced batch by batch - so the rows cost ONE memory latency
+        // instead of one per batch (measured: the two-deep pipeline spent 11-15 k cycles here, three exposed round trips)
+        f32x4 xq[6][2][4];
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rt_gload(xq[c][hf][i], xr[i] + 64 * c + 32 * hf);
 #define LN_WAIT(src, n_)                                                                                             \
     rt_wait4<n_>(src[0][0], src[0][1], src[0][2], src[0][3]);                                                         \
     rt_wait4<n_>(src[1][0], src[1][1], src[1][2], src[1][3]);
@@ -178,26 +183,19 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
     }                                                                                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                     \
         a[4 * (c_) + j] = *reinterpret_cast<const bf16x8 *>(stg + r * RT_STG_ROW + 32 * j + 16 * h);
-        LN_LOAD(xa, 0)
-        LN_LOAD(xb, 1)
-        LN_WAIT(xa, 8)                 // the 8 loads of the younger batch may still be in flight
-        LN_EMIT(xa, 0)
-        LN_LOAD(xa, 2)
-        LN_WAIT(xb, 8)
-        LN_EMIT(xb, 1)
-        LN_LOAD(xb, 3)
-        LN_WAIT(xa, 8)
-        LN_EMIT(xa, 2)
-        LN_LOAD(xa, 4)
-        LN_WAIT(xb, 8)
-        LN_EMIT(xb, 3)
-        LN_LOAD(xb, 5)
-        LN_WAIT(xa, 8)
-        LN_EMIT(xa, 4)
-        LN_WAIT(xb, 0)
-        LN_EMIT(xb, 5)
+        LN_WAIT(xq[0], 40)             // batch c has landed once at most 8 (5 - c) younger loads are outstanding
+        LN_EMIT(xq[0], 0)
+        LN_WAIT(xq[1], 32)
+        LN_EMIT(xq[1], 1)
+        LN_WAIT(xq[2], 24)
+        LN_EMIT(xq[2], 2)
+        LN_WAIT(xq[3], 16)
+        LN_EMIT(xq[3], 3)
+        LN_WAIT(xq[4], 8)
+        LN_EMIT(xq[4], 4)
+        LN_WAIT(xq[5], 0)
+        LN_EMIT(xq[5], 5)
 #undef LN_WAIT
-#undef LN_LOAD
 #undef LN_EMIT
     }
 };
@@ -251,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
     unsigned long long p_pro = 0, p_wait = 0, p_mma = 0, p_epi = 0;
 #endif
     RT_STAMP(t_begin);
+    typename Epi::State est;
     bf16x8 a[RT_KS];
     if (KC == 1) {            // one K chunk: the fragments are loaded once, before any accumulator is live
         RT_STAMP(t_p0);
@@ -290,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
                     wnext += RT_GK * RT_STEP_ELEMS;
                     issued++;
                 }
+                // the epilogue's own loads (the residual rows of x) go out one group early: all but the last four A fragments
+                // are dead by now, and 24 MFMAs per wave cover most of the memory latency
+                if (Epi::PREFETCH && nt_per_part == 1 && kg == RT_NG - 1 && kc == KC - 1) epi.prefetch(est, row0, nt0 + nt, lane, M);
                 const char *bb = rt_smem + buf * RT_GROUP_BYTES + lane * 16;
                 // fragment triples, software-pipelined by hand: the three ds_read_b128 of triple i + 1 are issued BEFORE the
                 // three MFMAs of triple i (96 cycles of matrix work cover the LDS latency); left alone hipcc reads two
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
 #pragma unroll
             for (int s = 0; s < RT_SL; s++) asm volatile("" ::"v"(acc[s]));
         } else
-            epi.tile(acc, row0, nt0 + nt, stg, vec_epi + RT_NT * nt_per_part, lane, M);
+            epi.tile(acc, est, row0, nt0 + nt, stg, vec_epi + RT_NT * nt_per_part, lane, M);
         RT_STAMP(t_e1);
         RT_ACC(p_epi, t_e1, t_e0);
     }
@@ -347,16 +349,27 @@ struct EpiResidual {
     float2 *stats;
     int extra_floats() const { return 0; }
     __device__ __forceinline__ void fill_extra(float *, int) const {}
-    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+    struct State {
+        f32x4 xv[RT_SL][4];
+    };
+    static constexpr bool PREFETCH = true;
+    __device__ __forceinline__ void prefetch(State &st, int row0, int nt, int lane, int M) const {
+        const int q = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float *px = x + (long long)min(row0 + 8 * i + q, M - 1) * VD + RT_NT * nt + 4 * p;
+#pragma unroll
+            for (int s = 0; s < RT_SL; s++) rt_gload(st.xv[s][i], px + 32 * s);
+        }
+    }
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &st, int row0, int nt, char *stg, const float *, int lane, int M) const {
         const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
         float *px[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) px[i] = x + (long long)min(row0 + 8 * i + q, M - 1) * VD + RT_NT * nt + 4 * p;
-        f32x4 xv[RT_SL][4];
-#pragma unroll
-        for (int s = 0; s < RT_SL; s++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) rt_gload(xv[s][i], px[i] + 32 * s);
+        f32x4 (&xv)[RT_SL][4] = st.xv;
+        // all 24 loads are older than anything issued since (the last group's LDS-DMA pieces included): one wait covers them
+        rt_wait4<0>(xv[0][0], xv[0][1], xv[0][2], xv[0][3]);
         float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < RT_SL; s++) {
@@ -364,14 +377,7 @@ struct EpiResidual {
             for (int g = 0; g < 4; g++)
                 *reinterpret_cast<float4 *>(stg + r * RT_STG_ROW + 32 * g + 16 * h) =
                     make_float4(acc[s][4 * g + 0], acc[s][4 * g + 1], acc[s][4 * g + 2], acc[s][4 * g + 3]);
-            // slice s of x has landed once at most 4 (5 - s) younger loads are outstanding (stores issued since only lower
-            // the count that is actually needed, never raise it: the wait is conservative)
-            if (s == 0) rt_wait4<20>(xv[0][0], xv[0][1], xv[0][2], xv[0][3]);
-            if (s == 1) rt_wait4<16>(xv[1][0], xv[1][1], xv[1][2], xv[1][3]);
-            if (s == 2) rt_wait4<12>(xv[2][0], xv[2][1], xv[2][2], xv[2][3]);
-            if (s == 3) rt_wait4<8>(xv[3][0], xv[3][1], xv[3][2], xv[3][3]);
-            if (s == 4) rt_wait4<4>(xv[4][0], xv[4][1], xv[4][2], xv[4][3]);
-            if (s == 5) rt_wait4<0>(xv[5][0], xv[5][1], xv[5][2], xv[5][3]);
+            if (s > 0) rt_wait4<0>(xv[s][0], xv[s][1], xv[s][2], xv[s][3]);      // names the registers only: everything has landed
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float4 d = *reinterpret_cast<const float4 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p);
@@ -432,7 +438,10 @@ struct EpiGelu {
     int ldo;
     int extra_floats() const { return 0; }
     __device__ __forceinline__ void fill_extra(float *, int) const {}
-    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+    struct State {};
+    static constexpr bool PREFETCH = false;
+    __device__ __forceinline__ void prefetch(State &, int, int, int, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &, int row0, int nt, char *stg, const float *, int lane, int M) const {
         const int q = lane >> 3, r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int pp = 0; pp < 3; pp++) {
@@ -459,7 +468,10 @@ struct EpiPatch {
     int cells, T;
     int extra_floats() const { return 0; }
     __device__ __forceinline__ void fill_extra(float *, int) const {}
-    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *, int lane, int M) const {
+    struct State {};
+    static constexpr bool PREFETCH = false;
+    __device__ __forceinline__ void prefetch(State &, int, int, int, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &, int row0, int nt, char *stg, const float *, int lane, int M) const {
         const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
         float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
         long long orow[4];
@@ -517,7 +529,10 @@ struct EpiQKV {
             rope[48 * G + i] = sinb[(long long)p * VHD + 16 + dd];
         }
     }
-    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], int row0, int nt, char *stg, const float *rope, int lane, int M) const {
+    struct State {};
+    static constexpr bool PREFETCH = false;
+    __device__ __forceinline__ void prefetch(State &, int, int, int, int) const {}
+    __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &, int row0, int nt, char *stg, const float *rope, int lane, int M) const {
         const int q8 = lane >> 3, r = lane & 31, h = lane >> 5;
         const int which = nt >> 1;
         bf16 *dst = which == 0 ? q : (which == 1 ? k : v);

@@ -13,17 +13,24 @@ import sys
 
 KEEP = ("selector_saliency", "gather_refine", "sim_argmax", "bn_tokens", "preprocess_kernel", "select_keypoints",
         "intensity_kernel", "match_finalize", "gather_kernel", "gemm_ares_kernel", "gemm_bf16_kernel", "attn_kernel", "ln_rows_kernel",
-        "mlp_fused_kernel", "im2patch", "refine_bf16_kernel", "selector_bf16_kernel", "preprocess_fast_kernel", "bn_tokens_reg_kernel", "keys_decode_kernel")
+        "mlp_fused_kernel", "im2patch", "refine_bf16_kernel", "selector_bf16_kernel", "preprocess_fast_kernel", "bn_tokens_reg_kernel", "keys_decode_kernel",
+        "gemm_rt_kernel", "prefix_rows_kernel")
 
 
 def short(name):
     for k in KEEP:
         if k in name:
             i = name.find(k)
-            j = name.find("(bool", i)
-            if j < 0:
-                j = name.find("(", i + len(k) + 40) if "<" in name[i:i + len(k) + 2] else name.find("(", i)
-            return name[i:j if j > 0 else None].replace("(anonymous namespace)::", "")
+            rest = name[i:].replace("(anonymous namespace)::", "")
+            if rest[len(k):len(k) + 1] == "<":           # keep the template arguments: they tell the instantiations apart
+                depth = 0
+                for j, ch in enumerate(rest):
+                    depth += ch == "<"
+                    depth -= ch == ">"
+                    if depth == 0 and ch == ">":
+                        return rest[:j + 1]
+            j = rest.find("(")
+            return rest[:j if j > 0 else None]
     return None
 
 

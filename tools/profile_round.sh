@@ -1,21 +1,23 @@
 #!/bin/bash
-# Regenerates the profile artefacts of a round on the GPU box (run from the repo root):  bash tools/profile_round.sh r01
+# Regenerates the profile artefacts of a round on the GPU box (run from the repo root):  bash tools/profile_round.sh r02
 # Writes gpurun_out/<tag>_*: copy the ones to be judged into profiles/ afterwards.  Raw traces stay in /tmp on the box.
 # rocprofv3 is always given the program itself after `--`; --pmc passes carry only --kernel-trace (no other trace domain).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 RX='selector_saliency|gather_refine|sim_argmax|bn_tokens|preprocess|select_keypoints|intensity_kernel|match_finalize|refine_bf16|selector_bf16|keys_decode'
+VRX='gemm_rt_kernel|attn_kernel|im2patch|prefix_rows|ln_rows'
 BENCH="$ROOT/bench.py --steps 5 --warmup 2"
+VIT="$ROOT/tools/bench_vit.py 448 64"
 
-echo "[1/5] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-echo "[2/5] kernel stats of the same command"
+echo "[1/6] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "[2/6] kernel stats of the same command"
 rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats -d /tmp/ks -o x --output-format csv -- python $BENCH --no-cpu-baseline --no-vit > /dev/null 2>&1
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
-echo "[3/5] HBM traffic + stall counters (separate --pmc passes)"
+echo "[3/6] HBM traffic + stall counters (separate --pmc passes)"
 rm -rf /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4
 P="--kernel-trace --kernel-include-regex $RX --output-format csv -o x"
 rocprofv3 --pmc FETCH_SIZE $P -d /tmp/pm1 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
@@ -25,11 +27,21 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_I
 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES $P -d /tmp/pm4 \
   -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4 > /dev/null
-echo "[4/5] ViT alone"
-python $ROOT/tools/bench_vit.py 448 64 > $OUT/${TAG}_vit_bench.txt
-rm -rf /tmp/kv && rocprofv3 --kernel-trace --stats -d /tmp/kv -o x --output-format csv -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
+echo "[4/6] ViT alone: bench, kernel stats, counters of the HEAD kernels"
+python $VIT > $OUT/${TAG}_vit_bench.txt
+python $ROOT/tools/bench_vit.py 448 1 8 41 >> $OUT/${TAG}_vit_bench.txt
+rm -rf /tmp/kv && rocprofv3 --kernel-trace --stats -d /tmp/kv -o x --output-format csv -- python $VIT > /dev/null 2>&1
 cp $(find /tmp/kv -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_vit_kernel_stats.csv
-echo "[5/5] library yardstick + bandwidth probe (context for the roofline fractions, not product code)"
+rm -rf /tmp/pv1 /tmp/pv2 /tmp/pv3 /tmp/pv4
+PV="--kernel-trace --kernel-include-regex $VRX --output-format csv -o x"
+rocprofv3 --pmc FETCH_SIZE $PV -d /tmp/pv1 -- python $VIT > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE $PV -d /tmp/pv2 -- python $VIT > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU $PV -d /tmp/pv3 -- python $VIT > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES GRBM_GUI_ACTIVE $PV -d /tmp/pv4 -- python $VIT > /dev/null 2>&1
+python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_vit.json /tmp/pv1 /tmp/pv2 /tmp/pv3 /tmp/pv4 > /dev/null
+echo "[5/6] single-frame latency"
+python $ROOT/tools/bench_latency.py > $OUT/${TAG}_latency.json 2>/dev/null
+echo "[6/6] library yardstick + bandwidth probe (context for the roofline fractions, not product code)"
 python $ROOT/tools/yardstick_vit.py > $OUT/${TAG}_yardstick.txt
 python $ROOT/tools/bw_probe.py >> $OUT/${TAG}_yardstick.txt
 echo done
