@@ -137,15 +137,20 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
                                                             int *__restrict__ nn12, float *__restrict__ s12,
                                                             int *__restrict__ nn21, float *__restrict__ s21,
                                                             float *__restrict__ second12,
-                                                            unsigned long long *__restrict__ keys) {
+                                                            unsigned long long *__restrict__ keys, int n_pairs, int qblocks) {
     __shared__ __attribute__((aligned(16))) float Cs[2 * CB * LDD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int dir = blockIdx.y;
-    const long long pair = blockIdx.z;
+    // XCD-aware order (speed only): the query blocks of a pair stream the same candidates; blocks b and b + 8 share an XCD
+    // (round-robin dispatch), so pair p goes to XCD p % 8 and its query blocks take consecutive slots there - the candidate
+    // tiles come from that XCD's L2 after the first block (PMC before: 785 MB fetched for 157 MB of descriptors)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long pair = (long long)(slot / qblocks) * 8 + xcd;
+    if (pair >= n_pairs) return;
     const float *q = dir == 0 ? desc1 + pair * stride1 : desc2 + pair * stride2;
     const float *c = dir == 0 ? desc2 + pair * stride2 : desc1 + pair * stride1;
     const int nq = dir == 0 ? n1 : n2, nc = dir == 0 ? n2 : n1;
-    const int q0 = blockIdx.x * QB;
+    const int q0 = (slot % qblocks) * QB;
     if (q0 >= nq) return;
     int *o_idx = (dir == 0 ? nn12 + pair * n1 : nn21 + pair * n2);
     float *o_val = dir == 0 ? (s12 ? s12 + pair * n1 : nullptr) : (s21 ? s21 + pair * n2 : nullptr);
@@ -344,7 +349,7 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
                                 void *stream) {
     if (!desc1 || !desc2 || !nn12 || !nn21 || n1 <= 0 || n2 <= 0 || n_pairs <= 0) return SSLAM_E_INVALID;
     if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15 || (stride1 & 3) || (stride2 & 3)) return SSLAM_E_INVALID;
-    if (n_pairs > 65535) return SSLAM_E_UNSUPPORTED;
+    if ((long long)n_pairs * ((((n1 > n2 ? n1 : n2) + QB - 1) / QB)) > 0x7ffffff0LL / 8) return SSLAM_E_UNSUPPORTED;
     // variant: 0 = by batch size, 1 = S per direction (no scratch memory), 2 = S once + 64-bit key reduction
     const char *env = getenv("SSLAM_M1_VARIANT");
     const int forced = env ? atoi(env) : 0;
@@ -357,8 +362,9 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
             (void)hipFreeAsync(keys, st);
             return SSLAM_E_LAUNCH;
         }
-        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((n1 + QB - 1) / QB, 1, n_pairs), dim3(NTM), 0, st, desc1, stride1, n1,
-                           desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys);
+        const int qb1 = (n1 + QB - 1) / QB;
+        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((unsigned)((n_pairs + 7) / 8 * 8 * qb1), 1, 1), dim3(NTM), 0, st, desc1, stride1, n1,
+                           desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys, n_pairs, qb1);
         g_sslam_launches++;
         bool ok = hipGetLastError() == hipSuccess;
         if (ok) {
@@ -371,8 +377,9 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
         return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
     }
     const int nmax = n1 > n2 ? n1 : n2;
-    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((nmax + QB - 1) / QB, 2, n_pairs), dim3(NTM), 0, st, desc1, stride1, n1,
-                       desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr);
+    const int qbm = (nmax + QB - 1) / QB;
+    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((unsigned)((n_pairs + 7) / 8 * 8 * qbm), 2, 1), dim3(NTM), 0, st, desc1, stride1, n1,
+                       desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr, n_pairs, qbm);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }
