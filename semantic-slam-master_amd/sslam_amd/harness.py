@@ -41,7 +41,7 @@ class SequenceMatcher:
         """One image -> numpy dict with the reference's keys (visualize_matches_sequence.py:97-104)."""
         from PIL import Image
         image = Image.open(image_path).convert("RGB")
-        out = self.extract_batch(np.asarray(image)[None])
+        out = self.extract_batch(np.array(image)[None])
         res = {k: v[0].cpu().numpy() for k, v in out.items()}
         res["image"] = image
         return res

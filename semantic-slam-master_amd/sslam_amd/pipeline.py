@@ -164,15 +164,11 @@ class SequencePipeline:
         if self.vit_hip is None:
             raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
         if vit_chunk is None:
-            vit_chunk = max(1, (253 * 128) // (N_PREFIX + self.cfg.grid ** 2))
+            vit_chunk = self.vit_hip.chunk_frames(self.cfg.input_size)
         out = torch.empty((images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT), dtype=torch.float32, device=self.device)
         for a in range(0, images_u8.shape[0], vit_chunk):
             b = min(a + vit_chunk, images_u8.shape[0])
-            x = self.preprocess(images_u8[a:b])
-            need = lib.vit_workspace_bytes(b - a, self.cfg.input_size)
-            if self.vit_hip._ws is None or self.vit_hip._ws.numel() < need:
-                self.vit_hip._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self.vit_hip.forward_features(x, out=out[a:b])
+            self.vit_hip.forward_features(self.preprocess(images_u8[a:b]), out=out[a:b], chunk=vit_chunk)
         return out
 
     def features(self, tokens: torch.Tensor, bf16_copy: bool = False):

@@ -51,8 +51,14 @@ class HipViT:
     def _f32(self, t):
         return self._hold(t.detach().to(self.device, torch.float32).contiguous())
 
-    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed)."""
+    @staticmethod
+    def chunk_frames(size: int) -> int:
+        """Frames per launch group: just under 256 row tiles of 128 tokens, i.e. ONE round of the GEMM workgroups at two per CU
+        (41 frames at 448 x 448: 13.8 k frames/s against 12.8 k at 64 frames = 1.54 rounds)."""
+        return max(1, (253 * 128) // (5 + (size // 16) ** 2))
+
+    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group."""
         n, _, s, s2 = images.shape
         assert s == s2 and s % 16 == 0 and images.is_cuda
         g = s // 16
@@ -60,7 +66,13 @@ class HipViT:
             cos, sin = self.vit.rope_tables(g, g, self.device)
             self._rope[g] = (cos.float().contiguous(), sin.float().contiguous())
         self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
-        need = lib.vit_workspace_bytes(n, s)
+        step = chunk or self.chunk_frames(s)
+        need = lib.vit_workspace_bytes(min(n, step), s)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return lib.vit_forward(images.detach().float().contiguous(), self.w, self._ws, out=out)
+        x = images.detach().float().contiguous()
+        if out is None:
+            out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
+        for a in range(0, n, step):
+            lib.vit_forward(x[a:a + step], self.w, self._ws, out=out[a:a + step])
+        return out

@@ -39,7 +39,7 @@ def test_vit_definition_matches_transformers_dinov3():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,frames", [(448, 2), (224, 3), (640, 1)])
+@pytest.mark.parametrize("size,frames", [(448, 2), (224, 3), (640, 1), (448, 12), (224, 48)])   # the last two: the throughput launch shapes (3 / 4 column tiles per workgroup)
 def test_hip_vit_matches_fp32_definition(size, frames):
     from sslam_amd import lib
     from sslam_amd.vit_hip import HipViT

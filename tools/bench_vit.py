@@ -18,12 +18,12 @@ chunks = [int(a) for a in sys.argv[2:]] or [8, 16, 32, 64, 128]
 for n in chunks:
     x = torch.randn(n, 3, size, size, device="cuda")
     for _ in range(2):
-        hv.forward_features(x)
+        hv.forward_features(x, chunk=n)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        hv.forward_features(x)
+        hv.forward_features(x, chunk=n)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"size {size} chunk {n:4d}: {dt*1e3:8.3f} ms  {n/dt:9.1f} frames/s  {n*flop/dt/1e12:7.1f} TFLOP/s", flush=True)
