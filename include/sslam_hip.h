@@ -198,6 +198,8 @@ typedef struct {
     const float *bup;
     const void *wdown;
     const float *bdown;
+    const void *wmlp;      /* optional (may be NULL): up_proj + down_proj as ONE stream for the fused MLP kernel
+                              (sslam_vit_pack_mlp_host); used for batches of more than ~8 frames, wup / wdown otherwise */
 } sslam_vit_layer_t;
 typedef struct {
     const void *patch_w;
@@ -207,6 +209,9 @@ typedef struct {
 } sslam_vit_weights_t;
 /* host helper: fp32 nn.Linear weight (n_out, k_in), n_out % 192 == 0, k_in % 384 == 0 -> the packed bf16 image above */
 int sslam_vit_pack_linear_host(const float *w, int n_out, int k_in, uint16_t *out);
+/* host helper: up_proj (1536, 384) + down_proj (384, 1536) [rows times row_scale = LayerScale 2, or NULL] -> the 2 x 1536 x 384
+ * bf16 stream of the fused MLP kernel (per 64-wide hidden chunk: 48 KB of up rows, then 48 KB of down columns) */
+int sslam_vit_pack_mlp_host(const float *w_up, const float *w_down, const float *row_scale, uint16_t *out);
 long long sslam_vit_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
                       void *workspace, long long workspace_bytes, float *tokens_out, void *stream);

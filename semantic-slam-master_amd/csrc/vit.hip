@@ -571,6 +571,183 @@ struct EpiQKV {
     }
 };
 
+// ------------------------------------------------------------------------- fused MLP: LN2 -> up -> GELU -> down -> residual
+// One launch for the whole MLP half of a block: the 1536-wide hidden activation never leaves the chip (it was 155 MB
+// written + 263 MB read per layer and 64 frames, a quarter of the layer's HBM traffic, and two of its five launches).
+// Workgroup = 8 waves = 4 wave PAIRS x 32 tokens, one per CU.  Both waves of a pair keep LayerNorm(x) of their 32 tokens as
+// bf16 fragments in registers (ProLN, 96 VGPRs).  The hidden dimension is walked in 24 chunks of 64; per chunk
+//   U: wave `hf` of the pair multiplies hidden slice hf (32 units) over K = 384: H^T = W1 . Xn^T, hidden on accumulator rows,
+//      the token on the lane (24 MFMAs), adds the bias (initial accumulator), applies GELU in registers;
+//   X: the 32 x 32 bf16 tile IS the B operand of the next product for its two k-steps (accumulator registers 8 s .. 8 s + 7 of a
+//      tile are the fragment of k-step s, with the k order 16 s + 8 (j >> 2) + 4 h + (j & 3) - W2 is packed in that order), so the
+//      only exchange is the partner's tile, 2 KB per wave through LDS;
+//   D: out^T += W2[:, chunk] . H^T for the wave's half of the 384 outputs (6 slices x 4 k-steps = 24 MFMAs, 96 accumulators).
+// The weights of a chunk are 2 x 48 KB of contiguous memory (sslam_vit_pack_mlp_host) streamed by LDS-DMA into a 2 x 48 KB
+// ring shared by all eight waves: group g + 1 is in flight while group g is multiplied, one barrier per group.  The
+// epilogue is EpiResidual (x += out, LayerNorm partial sums of the new rows).
+constexpr int MF_GROUP_BYTES = 48 * 1024, MF_CHUNKS = VMLP / 64;
+constexpr int MF_XCH_BYTES = 8 * 2 * 1024;                                   // per wave: two 1 KB fragments
+constexpr int MF_LDS_BYTES = 2 * MF_GROUP_BYTES + 8 * RT_STG_BYTES + 4 * (2 * VD + VMLP + VD);   // ring + staging (overlaid by the exchange) + vectors
+
+__device__ __forceinline__ void mf_dma_group(const bf16 *src, char *dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {                                            // 48 pieces of 1 KB over 8 waves
+        const int piece = wave * 6 + i;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 512 + lane * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_fused_kernel(ProLN pro, const bf16 *__restrict__ Wp, const float *__restrict__ b_up, int M,
+                                                           EpiResidual epi) {
+    extern __shared__ __attribute__((aligned(16))) char mf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave >> 1, hf = wave & 1;
+    const int row0 = blockIdx.x * RT_BM + pair * 32;
+    char *stg = mf_smem + 2 * MF_GROUP_BYTES + wave * RT_STG_BYTES;
+    char *xch = mf_smem + 2 * MF_GROUP_BYTES;                                 // exchange tiles overlay the staging tiles (main loop only)
+    float *vec_pro = reinterpret_cast<float *>(mf_smem + 2 * MF_GROUP_BYTES + 8 * RT_STG_BYTES);
+    float *vec_b1 = vec_pro + 2 * VD, *vec_b2 = vec_b1 + VMLP;
+
+    const bf16 *wnext = Wp;
+    mf_dma_group(wnext, mf_smem, wave, lane);
+    wnext += MF_GROUP_BYTES / 2;
+    for (int i = tid; i < VD; i += 512) {
+        vec_pro[i] = pro.gamma[i];
+        vec_pro[VD + i] = pro.beta[i];
+        vec_b2[i] = epi.bias[i];
+    }
+    for (int i = tid; i < VMLP; i += 512) vec_b1[i] = b_up[i];
+    __syncthreads();
+
+#ifdef SSLAM_RT_PROBE
+    unsigned long long p_pro = 0, p_wait = 0, p_mma = 0, p_epi = 0, p_gelu = 0;
+#endif
+    RT_STAMP(t_begin);
+    bf16x8 a[RT_KS];
+    pro.load(a, row0, 0, stg, vec_pro, lane, M);
+    RT_STAMP(t_pro1);
+    RT_ACC(p_pro, t_pro1, t_begin);
+    typename EpiResidual::State est;
+    f32x16 acc[RT_SL];            // this wave's 192 outputs of its 32 tokens; starts from the (LayerScale-folded) bias
+#pragma unroll
+    for (int s = 0; s < RT_SL; s++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(vec_b2 + RT_NT * hf + 32 * s + 8 * g + 4 * h);
+            acc[s][4 * g + 0] = b.x;
+            acc[s][4 * g + 1] = b.y;
+            acc[s][4 * g + 2] = b.z;
+            acc[s][4 * g + 3] = b.w;
+        }
+    __syncthreads();             // every wave is done with its staging tile: the exchange tiles may overlay them
+
+    int buf = 0;
+    for (int c = 0; c < MF_CHUNKS; c++) {
+        // ---- U: hidden slice hf of chunk c ------------------------------------------------------------------------------
+        RT_STAMP(t_u0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // group U_c has landed; everyone has left the other buffer (D_{c-1})
+        RT_STAMP(t_u1);
+        RT_ACC(p_wait, t_u1, t_u0);
+        mf_dma_group(wnext, mf_smem + (buf ^ 1) * MF_GROUP_BYTES, wave, lane);          // D_c
+        wnext += MF_GROUP_BYTES / 2;
+        f32x16 hacc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 b = *reinterpret_cast<const float4 *>(vec_b1 + 64 * c + 32 * hf + 8 * g + 4 * h);
+            hacc[4 * g + 0] = b.x;
+            hacc[4 * g + 1] = b.y;
+            hacc[4 * g + 2] = b.z;
+            hacc[4 * g + 3] = b.w;
+        }
+        {
+            const char *bb = mf_smem + buf * MF_GROUP_BYTES + hf * 1024 + lane * 16;
+            bf16x8 wa[2], wb[2];
+#define MF_LDU(dst, i_) _Pragma("unroll") for (int t = 0; t < 2; t++) dst[t] = *reinterpret_cast<const bf16x8 *>(bb + (2 * (i_) + t) * 2048);
+#define MF_MMU(src, i_)                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < 2; t++) hacc = mfma_bf16(src[t], a[2 * (i_) + t], hacc);        \
+    __builtin_amdgcn_sched_barrier(0);
+            MF_LDU(wa, 0)
+            MF_LDU(wb, 1) MF_MMU(wa, 0)
+            MF_LDU(wa, 2) MF_MMU(wb, 1)
+            MF_LDU(wb, 3) MF_MMU(wa, 2)
+            MF_LDU(wa, 4) MF_MMU(wb, 3)
+            MF_LDU(wb, 5) MF_MMU(wa, 4)
+            MF_LDU(wa, 6) MF_MMU(wb, 5)
+            MF_LDU(wb, 7) MF_MMU(wa, 6)
+            MF_LDU(wa, 8) MF_MMU(wb, 7)
+            MF_LDU(wb, 9) MF_MMU(wa, 8)
+            MF_LDU(wa, 10) MF_MMU(wb, 9)
+            MF_LDU(wb, 11) MF_MMU(wa, 10)
+            MF_MMU(wb, 11)
+#undef MF_LDU
+#undef MF_MMU
+        }
+        buf ^= 1;
+        RT_STAMP(t_u2);
+        RT_ACC(p_mma, t_u2, t_u1);
+        // GELU in registers; registers 8 s .. 8 s + 7 of the tile are the B fragment of k-step 2 hf + s of the chunk
+        u32x4 own[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) own[s][j] = pack_bf16x2(gelu_poly(hacc[8 * s + 2 * j]), gelu_poly(hacc[8 * s + 2 * j + 1]));
+#pragma unroll
+        for (int s = 0; s < 2; s++) *reinterpret_cast<u32x4 *>(xch + (wave * 2 + s) * 1024 + lane * 16) = own[s];
+        // ---- D: the wave's 192 outputs over the 64 hidden units of the chunk ---------------------------------------------
+        RT_STAMP(t_d0);
+        RT_ACC(p_gelu, t_d0, t_u2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // group D_c has landed, U_c is consumed, both tiles of every pair are written
+        RT_STAMP(t_d1);
+        RT_ACC(p_wait, t_d1, t_d0);
+        if (c + 1 < MF_CHUNKS) {
+            mf_dma_group(wnext, mf_smem + (buf ^ 1) * MF_GROUP_BYTES, wave, lane);      // U_{c+1}
+            wnext += MF_GROUP_BYTES / 2;
+        }
+        u32x4 other[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) other[s] = *reinterpret_cast<const u32x4 *>(xch + ((wave ^ 1) * 2 + s) * 1024 + lane * 16);
+        {
+            const char *bb = mf_smem + buf * MF_GROUP_BYTES + (6 * hf) * 1024 + lane * 16;
+            bf16x8 wa[3], wb[3];
+            // k-step s4 (16 hidden units) of the chunk belongs to the wave with hf == s4 >> 1
+#define MF_PB(s4_) __builtin_bit_cast(bf16x8, ((s4_) >> 1) == hf ? own[(s4_) & 1] : other[(s4_) & 1])
+#define MF_LDD(dst, i_) _Pragma("unroll") for (int t = 0; t < 3; t++) dst[t] = *reinterpret_cast<const bf16x8 *>(bb + (((i_) >> 1) * 12 + ((i_) & 1) * 3 + t) * 1024);
+#define MF_MMD(src, i_)                                                                                              \
+    _Pragma("unroll") for (int t = 0; t < 3; t++) acc[((i_) & 1) * 3 + t] = mfma_bf16(src[t], MF_PB((i_) >> 1), acc[((i_) & 1) * 3 + t]); \
+    __builtin_amdgcn_sched_barrier(0);
+            MF_LDD(wa, 0)
+            MF_LDD(wb, 1) MF_MMD(wa, 0)
+            MF_LDD(wa, 2) MF_MMD(wb, 1)
+            MF_LDD(wb, 3) MF_MMD(wa, 2)
+            MF_LDD(wa, 4) MF_MMD(wb, 3)
+            MF_LDD(wb, 5) MF_MMD(wa, 4)
+            MF_LDD(wa, 6) MF_MMD(wb, 5)
+            MF_LDD(wb, 7) MF_MMD(wa, 6)
+            MF_MMD(wb, 7)
+#undef MF_LDD
+#undef MF_MMD
+#undef MF_PB
+        }
+        buf ^= 1;
+        RT_STAMP(t_d2);
+        RT_ACC(p_mma, t_d2, t_d1);
+    }
+    __syncthreads();             // the exchange tiles are dead: the staging tiles take the region back
+    RT_STAMP(t_e0);
+    epi.prefetch(est, row0, hf, lane, M);
+    epi.tile(acc, est, row0, hf, stg, nullptr, lane, M);
+#ifdef SSLAM_RT_PROBE
+    if (tid == 0 && blockIdx.x < 2048) {
+        unsigned long long *o = g_rt_probe + 8 * blockIdx.x;
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        o[0] = t_end - t_begin;
+        o[1] = p_pro; o[2] = p_wait; o[3] = p_mma; o[4] = t_end - t_e0; o[5] = p_gelu;
+    }
+#endif
+}
+
 // --------------------------------------------------------------------------------------------- LayerNorm
 // one wave per row of 384: lane l holds elements l*2 + 128*j .. (float2 x 3); fp32 two-pass statistics
 template <bool OUT_BF16>
@@ -859,6 +1036,37 @@ extern "C" int sslam_vit_pack_linear_host(const float *w, int n_out, int k_in, u
     return SSLAM_OK;
 }
 
+// fused-MLP weight stream: per 64-wide hidden chunk c the 48 KB of up_proj rows [64 c, 64 c + 64) as [k-step 24][slice 2][lane][8]
+// followed by the 48 KB of down_proj columns [64 c, 64 c + 64) as [k-step 4][out slice 12][lane][8] with the k order of an
+// accumulator tile used as B operand: element j of lane half h of k-step s is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3).
+// row_scale (384 floats or NULL) multiplies the down_proj rows (LayerScale).
+extern "C" int sslam_vit_pack_mlp_host(const float *w_up, const float *w_down, const float *row_scale, uint16_t *out) {
+    if (!w_up || !w_down || !out) return SSLAM_E_INVALID;
+    auto bf = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        return (u & 0x7fffffffu) > 0x7f800000u ? (uint16_t)((u >> 16) | 0x40) : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    for (int c = 0; c < MF_CHUNKS; c++) {
+        uint16_t *up = out + (size_t)c * 2 * (MF_GROUP_BYTES / 2), *dn = up + MF_GROUP_BYTES / 2;
+        for (int ks = 0; ks < 24; ks++)
+            for (int sl = 0; sl < 2; sl++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int hid = 64 * c + 32 * sl + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                        up[((ks * 2 + sl) * 64 + l) * 8 + j] = bf(w_up[(size_t)hid * VD + k]);
+                    }
+        for (int s4 = 0; s4 < 4; s4++)
+            for (int sl = 0; sl < 12; sl++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int n = 32 * sl + (l & 31), hid = 64 * c + 16 * s4 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                        dn[((s4 * 12 + sl) * 64 + l) * 8 + j] = bf(w_down[(size_t)n * VMLP + hid] * (row_scale ? row_scale[n] : 1.0f));
+                    }
+    }
+    return SSLAM_OK;
+}
+
 #ifdef SSLAM_RT_PROBE
 extern "C" int sslam_probe_vit(unsigned long long *host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rt_probe), sizeof(unsigned long long) * 8 * 2048) == hipSuccess ? 0 : -3;
@@ -905,7 +1113,8 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
         g_sslam_launches++;
     }
     const float4 *st4 = (const float4 *)stats;
-    const bool small = (rows + RT_BM - 1) / RT_BM * 4 <= 256;     // <= 8 frames at 448 x 448: latency-shaped launches
+    const bool small = (rows + RT_BM - 1) / RT_BM * 4 <= 256;
+    const bool no_fused = getenv("SSLAM_VIT_NO_FUSED_MLP") != nullptr;      // A/B knob: the two-launch MLP     // <= 8 frames at 448 x 448: latency-shaped launches
     int rt_stop = 0;
 #ifdef SSLAM_RT_PROBE
     { const char *e = getenv("SSLAM_RT_STOP"); rt_stop = e ? atoi(e) : 0; }
@@ -922,6 +1131,14 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
         hipLaunchKernelGGL(attn_kernel, dim3((unsigned)((n_frames * VH + 7) / 8 * 8 * ((T + AQ - 1) / AQ))), dim3(256), 0, st, q, k, v, y, T, n_frames * VH);
         launch_rt<1, 1>(ProBf16{y, VD}, (const bf16 *)ly.wo, rows, VD, EpiResidual{ly.bo, x, stats}, st);
         if (rt_stop == 2) break;
+        if (ly.wmlp && !small && !no_fused) {
+            // LN2 -> up -> GELU -> down -> residual in one launch: the hidden activation stays on the chip
+            hipLaunchKernelGGL(mlp_fused_kernel, dim3((unsigned)((rows + RT_BM - 1) / RT_BM)), dim3(512), MF_LDS_BYTES, st,
+                               ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wmlp, ly.bup, (int)rows, EpiResidual{ly.bdown, x, stats});
+            if (rt_stop == 3 || rt_stop == 4) break;
+            g_sslam_launches += 4;
+            continue;
+        }
         if (small)
             launch_rt<1, 1>(ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wup, rows, VMLP, EpiGelu{ly.bup, hbuf, VMLP}, st);
         else

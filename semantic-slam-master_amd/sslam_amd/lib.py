@@ -29,7 +29,7 @@ class SslamHipError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "wup", "bup",
-                                          "wdown", "bdown")]
+                                          "wdown", "bdown", "wmlp")]
 
 
 class VitWeights(C.Structure):
@@ -59,7 +59,7 @@ EXPORTS = [
     "sslam_resample_table_host", "sslam_preprocess_u8", "sslam_bn_tokens", "sslam_selector_saliency",
     "sslam_select_keypoints", "sslam_gather", "sslam_refiner_layout", "sslam_refiner_pack_host", "sslam_refine",
     "sslam_gather_refine", "sslam_keypoint_intensity", "sslam_sim_argmax", "sslam_match_finalize",
-    "sslam_vit_pack_linear_host", "sslam_vit_workspace_bytes", "sslam_vit_forward",
+    "sslam_vit_pack_linear_host", "sslam_vit_pack_mlp_host", "sslam_vit_workspace_bytes", "sslam_vit_forward",
     "sslam_f32_to_bf16", "sslam_pack_conv3x3_bf16_host", "sslam_selector_saliency_bf16",
     "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
 ]
@@ -101,6 +101,7 @@ def lib():
         L.sslam_refine_bf16.argtypes = [p, ll, p, i, p, p]
         L.sslam_gather_refine_bf16.argtypes = [p, i, i, p, i, p, i, p, p]
         L.sslam_vit_pack_linear_host.argtypes = [p, i, i, p]
+        L.sslam_vit_pack_mlp_host.argtypes = [p, p, p, p]
         L.sslam_vit_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
@@ -381,6 +382,17 @@ def pack_vit_linear(w: np.ndarray) -> np.ndarray:
     w = np.ascontiguousarray(w, np.float32)
     out = np.empty(w.size, np.uint16)
     _check(lib().sslam_vit_pack_linear_host(w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data), "vit_pack_linear")
+    return out
+
+
+def pack_vit_mlp(w_up: np.ndarray, w_down: np.ndarray, row_scale: np.ndarray | None) -> np.ndarray:
+    """(1536, 384) up_proj + (384, 1536) down_proj [+ per-row scale of down_proj] -> the fused MLP kernel's weight stream."""
+    w_up, w_down = np.ascontiguousarray(w_up, np.float32), np.ascontiguousarray(w_down, np.float32)
+    assert w_up.shape == (1536, 384) and w_down.shape == (384, 1536)
+    rs = None if row_scale is None else np.ascontiguousarray(row_scale, np.float32)
+    out = np.empty(2 * 1536 * 384, np.uint16)
+    _check(lib().sslam_vit_pack_mlp_host(w_up.ctypes.data, w_down.ctypes.data, None if rs is None else rs.ctypes.data, out.ctypes.data),
+           "vit_pack_mlp")
     return out
 
 

@@ -37,6 +37,9 @@ class HipViT:
             ly.ln2_g, ly.ln2_b = f32(b.norm2.weight), f32(b.norm2.bias)
             ly.wup, ly.bup = bf(b.up_proj.weight), f32(b.up_proj.bias)
             ly.wdown, ly.bdown = bf(b.down_proj.weight * b.ls2[:, None]), f32(b.down_proj.bias * b.ls2)
+            ly.wmlp = self._hold(torch.from_numpy(lib.pack_vit_mlp(b.up_proj.weight.detach().float().cpu().numpy(),
+                                                                  b.down_proj.weight.detach().float().cpu().numpy(),
+                                                                  b.ls2.detach().float().cpu().numpy())).to(self.device))
         self.w.norm_g, self.w.norm_b = f32(vit.norm.weight), f32(vit.norm.bias)
 
     def _hold(self, t):
@@ -53,9 +56,10 @@ class HipViT:
 
     @staticmethod
     def chunk_frames(size: int) -> int:
-        """Frames per launch group: just under 256 row tiles of 128 tokens, i.e. ONE round of the GEMM workgroups at two per CU
-        (41 frames at 448 x 448: 13.8 k frames/s against 12.8 k at 64 frames = 1.54 rounds)."""
-        return max(1, (253 * 128) // (5 + (size // 16) ** 2))
+        """Frames per launch group: just under 2 x 253 row tiles of 128 tokens.  The GEMM launches run one workgroup per (row
+        tile, column half) at two per CU and the fused MLP one per row tile, so 506 tiles are whole rounds for all of them
+        (82 frames at 448 x 448: 14.8 k frames/s; 41 frames: 13.6 k; 64 frames = a partial round: 12.8 k)."""
+        return max(1, (506 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
         """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group."""

@@ -22,15 +22,17 @@ from sslam_amd.vit_hip import HipViT
 torch.manual_seed(0)
 hv = HipViT(DinoV3ViT().cuda().eval())
 img = torch.randn(n, 3, 448, 448, device=dev)
-names = ["lifetime", "prologue", "wait+barrier", "mfma loop", "epilogue"]
-for stop, label in [(1, "QKV (ProLN, EpiQKV)"), (2, "o_proj (ProBf16, EpiResidual)"), (3, "up (ProLN, EpiGelu)"), (4, "down (ProBf16 x4, EpiResidual)")]:
+names = ["lifetime", "prologue", "wait+barrier", "mfma loop", "epilogue", "gelu+exchange (fused MLP)"]
+for stop, label in [(1, "QKV (ProLN, EpiQKV)"), (2, "o_proj (ProBf16, EpiResidual)"), (3, "MLP: fused kernel, or up (ProLN, EpiGelu) with SSLAM_VIT_NO_FUSED_MLP=1"), (4, "down (ProBf16 x4, EpiResidual) with SSLAM_VIT_NO_FUSED_MLP=1")]:
     os.environ["SSLAM_RT_STOP"] = str(stop)
     for _ in range(2):
-        hv.forward_features(img)
+        hv.forward_features(img, chunk=n)
     torch.cuda.synchronize()
     buf = np.zeros(8 * 2048, np.uint64)
     assert L.sslam_probe_vit(ctypes.c_void_p(buf.ctypes.data)) == 0
     t = buf.reshape(2048, 8).astype(np.float64)
+    if stop == 3 and not os.environ.get("SSLAM_VIT_NO_FUSED_MLP"):
+        t = t[: (rows + 127) // 128]          # the fused kernel runs one workgroup per row tile; later entries are stale
     t = t[t[:, 0] > 0]
     print(f"{label}: {len(t)} workgroups")
     for i, nm in enumerate(names):
