@@ -9,9 +9,14 @@
 // at most ksize_v * ksize_h source pixels per keypoint and never materialises the resized image.
 #include <math.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PREC = 22;   // Pillow PRECISION_BITS = 32 - 8 - 2
 constexpr int TX = 64, TY = 16, MAXR = 64;
@@ -77,60 +82,63 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 
 // Fast path (horizontal taps <= 7, i.e. bilinear down to 1/3 or bicubic down to 2/3 of the input width):
 //  - a thread owns ONE output column for the whole tile, so its bounds / coefficients live in registers;
-//  - the <= 21 source bytes of a pixel are fetched as six aligned dwords and re-aligned with v_alignbyte
-//    (byte loads made the first version of this kernel TA-instruction bound at 1.36 TB/s);
-//  - the uint8 intermediate row is kept packed (R | G<<8 | B<<16) so the vertical pass reads one dword per tap.
+//  - the <= 21 source bytes of a pixel are fetched as one or two range-checked buffer loads (16 + 4 / 8 bytes) at the
+//    dword below the first byte and re-aligned with v_alignbyte (byte loads made the first version of this kernel
+//    TA-instruction bound at 1.36 TB/s); 32-bit offsets into ONE descriptor over the launch's frames: no 64-bit
+//    address arithmetic, no end-of-buffer branches (the descriptor returns 0 beyond the last dword);
+//  - every product is an 8-bit sample times a 22-bit coefficient: v_mad_i32_i24 (full rate) - the plain 32-bit
+//    multiply hipcc picks for `int * int` is quarter rate and was half of this kernel's VALU time;
+//  - the uint8 intermediate row is kept packed (R | G<<8 | B<<16) so the vertical pass reads one dword per tap;
+//  - the vertical coefficients of an output row are wave-uniform (a wave owns whole rows): scalar loads.
 //  - TAPS (3, 5 or 7) is the compile-time tap count: 640 -> 448 bilinear needs 5, so two of seven tap slots would be zeros.
 template <int TAPS, int TYT, int MAXRT>
-__global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__restrict__ img, int h, int w, int size,
-                                                               const int *__restrict__ bh, const int *__restrict__ ch, int ksh,
-                                                               const int *__restrict__ bv, const int *__restrict__ cv, int ksv,
-                                                               float *__restrict__ out) {
+__global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__restrict__ img, unsigned total_bytes, int h, int w,
+                                                               int size, const int *__restrict__ bh, const int *__restrict__ ch,
+                                                               int ksh, const int *__restrict__ bv, const int *__restrict__ cv,
+                                                               int ksv, float *__restrict__ out) {
     __shared__ unsigned tmp[MAXRT][TX];
     __shared__ float lut[3][256];
     const int tid = threadIdx.x;
-    const long long f = blockIdx.z;
+    const unsigned f = blockIdx.z;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TYT;
     const int ty1 = min(y0 + TYT, size) - 1;
     const int rmin = bv[2 * y0], rmax = bv[2 * ty1] + bv[2 * ty1 + 1];   // input rows [rmin, rmax)
     const int nrows = rmax - rmin;
-    const long long total_bytes = (long long)gridDim.z * h * w * 3;
-    const long long frame0 = f * h * w * 3;
+    // a dword that holds one valid byte lies inside the allocation's last page: the descriptor covers whole dwords
+    const __amdgpu_buffer_rsrc_t irs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), 0, (int)((total_bytes + 3u) & ~3u), 0x00020000);
     {
         const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
         for (int c = 0; c < 3; c++) lut[c][tid] = ((float)tid / 255.0f - mean[c]) / sd[c];
     }
-    const int xx = tid & (TX - 1), q = tid >> 6;                           // q = 0..3
+    const int xx = tid & (TX - 1), q = __builtin_amdgcn_readfirstlane(tid >> 6);   // q = 0..3: the wave
     const int ox = min(x0 + xx, size - 1);
     {
         const int xmin = bh[2 * ox], xn = bh[2 * ox + 1];
         constexpr int NW = (3 * TAPS + 3 + 3) / 4;                          // dwords covering 3*TAPS bytes at any alignment
         int kh[TAPS];
 #pragma unroll
-        for (int t = 0; t < TAPS; t++) kh[t] = t < xn ? ch[(long long)ox * ksh + t] : 0;
+        for (int t = 0; t < TAPS; t++) kh[t] = t < xn ? ch[ox * ksh + t] : 0;
+        const unsigned col0 = f * (unsigned)(h * w * 3) + (unsigned)(rmin * w + xmin) * 3u;
+        const unsigned rstride = (unsigned)w * 3u;
         // RB rows are fetched together (the pass is load-latency bound otherwise), then filtered one after the other
         constexpr int RB = 3;
         for (int rr0 = q; rr0 < nrows; rr0 += 4 * RB) {
-            unsigned wds[RB][NW];
+            unsigned wds[RB][8];
             int shv[RB];
 #pragma unroll
             for (int i = 0; i < RB; i++) {
                 const int rr = min(rr0 + 4 * i, nrows - 1);
-                const long long b0 = frame0 + ((long long)(rmin + rr) * w + xmin) * 3;
-                const long long a0 = b0 & ~3LL;
-                shv[i] = (int)(b0 & 3);
-#pragma unroll
-                for (int j = 0; j < NW; j++) {
-                    const long long a = a0 + 4 * j;
-                    unsigned v = 0;
-                    if (a + 4 <= total_bytes) {
-                        v = *reinterpret_cast<const unsigned *>(img + a);
-                    } else {
-                        for (int k = 0; k < 4; k++)
-                            if (a + k < total_bytes) v |= (unsigned)img[a + k] << (8 * k);
-                    }
-                    wds[i][j] = v;
+                const unsigned b0 = col0 + (unsigned)rr * rstride;
+                const int a0 = (int)(b0 & ~3u);
+                shv[i] = (int)(b0 & 3u);
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(irs, a0, 0, 0);
+                wds[i][0] = lo[0], wds[i][1] = lo[1], wds[i][2] = lo[2], wds[i][3] = lo[3];
+                if constexpr (NW == 5) wds[i][4] = __builtin_amdgcn_raw_buffer_load_b32(irs, a0, 16, 0);
+                if constexpr (NW == 6) {
+                    const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(irs, a0, 16, 0);
+                    wds[i][4] = hi[0], wds[i][5] = hi[1];
                 }
             }
 #pragma unroll
@@ -149,9 +157,9 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__r
                     const int r8 = (al[o >> 2] >> (8 * (o & 3))) & 255;
                     const int g8 = (al[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255;
                     const int b8 = (al[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255;
-                    s0 += r8 * kh[t];
-                    s1 += g8 * kh[t];
-                    s2 += b8 * kh[t];
+                    s0 += __mul24(r8, kh[t]);
+                    s1 += __mul24(g8, kh[t]);
+                    s2 += __mul24(b8, kh[t]);
                 }
                 tmp[rr][xx] = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16);
             }
@@ -162,19 +170,19 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__r
     if (x0 + xx < size) {
 #pragma unroll
         for (int j = 0; j < TYT / 4; j++) {
-            const int oy = y0 + q * (TYT / 4) + j;
+            const int oy = y0 + q * (TYT / 4) + j;                           // wave-uniform
             if (oy < size) {
                 const int ymin = bv[2 * oy] - rmin, yn = bv[2 * oy + 1];
-                const int *k = cv + (long long)oy * ksv;
+                const int *k = cv + oy * ksv;
                 int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
                 for (int t = 0; t < yn; t++) {
                     const unsigned p = tmp[ymin + t][xx];
                     const int kk = k[t];
-                    s0 += (int)(p & 255) * kk;
-                    s1 += (int)((p >> 8) & 255) * kk;
-                    s2 += (int)((p >> 16) & 255) * kk;
+                    s0 += __mul24((int)(p & 255), kk);
+                    s1 += __mul24((int)((p >> 8) & 255), kk);
+                    s2 += __mul24((int)((p >> 16) & 255), kk);
                 }
-                float *o = out + f * 3 * plane + (long long)oy * size + (x0 + xx);
+                float *o = out + (long long)f * 3 * plane + (long long)oy * size + (x0 + xx);
                 o[0] = lut[0][clip8(s0)];
                 o[plane] = lut[1][clip8(s1)];
                 o[2 * plane] = lut[2][clip8(s2)];
@@ -280,30 +288,40 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
     if (ksize_h <= 0 || ksize_v <= 0 || ksize_h > SSLAM_MAX_TAPS || ksize_v > SSLAM_MAX_TAPS) return SSLAM_E_INVALID;
     // input rows one output tile can need: TY output rows span TY*scale input rows plus the filter support
     if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
-    if (n > 65535) return SSLAM_E_UNSUPPORTED;
-    const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, n);
+    const bool aligned = !((uintptr_t)img & 3);
     // the fast kernel prefers 32-row tiles (less vertical-halo re-filtering) when their input rows fit its LDS buffer
     const bool tall = (32LL * h + size - 1) / size + ksize_v + 2 <= 64;
-    const dim3 grid32((size + TX - 1) / TX, (size + 31) / 32, n);
+    // launch groups: grid.z <= 65535 and, for the fast kernel, all byte offsets of a group inside one 32-bit descriptor
+    const long long fbytes = (long long)h * w * 3;
+    if (fbytes > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
+    const int per_group = (int)std::min<long long>(65535, std::max<long long>(1, 0xfffffff0LL / fbytes));
+    for (int n0 = 0; n0 < n; n0 += per_group) {
+        const int ng = std::min(per_group, n - n0);
+        const uint8_t *gi = img + (long long)n0 * fbytes;
+        float *go = out_chw + (long long)n0 * 3 * size * size;
+        const unsigned gbytes = (unsigned)(ng * fbytes);
+        const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, ng);
+        const dim3 grid32((size + TX - 1) / TX, (size + 31) / 32, ng);
 #define FAST(T)                                                                                                        \
     {                                                                                                                  \
         if (tall)                                                                                                      \
-            hipLaunchKernelGGL((preprocess_fast_kernel<T, 32, 64>), grid32, dim3(256), 0, (hipStream_t)stream, img, h, w, size, \
-                               bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);                       \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, 32, 64>), grid32, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
+                               size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, go);                      \
         else                                                                                                           \
-            hipLaunchKernelGGL((preprocess_fast_kernel<T, TY, MAXR>), grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, \
-                               bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw);                       \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, TY, MAXR>), grid, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
+                               size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, go);                      \
     }
-    if (ksize_h <= 3 && !((uintptr_t)img & 3))
-        FAST(3)
-    else if (ksize_h <= 5 && !((uintptr_t)img & 3))
-        FAST(5)
-    else if (ksize_h <= 7 && !((uintptr_t)img & 3))
-        FAST(7)
-    else
-        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, h, w, size, bounds_h, coefs_h,
-                           ksize_h, bounds_v, coefs_v, ksize_v, out_chw);
+        if (ksize_h <= 3 && aligned)
+            FAST(3)
+        else if (ksize_h <= 5 && aligned)
+            FAST(5)
+        else if (ksize_h <= 7 && aligned)
+            FAST(7)
+        else
+            hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, gi, h, w, size, bounds_h, coefs_h,
+                               ksize_h, bounds_v, coefs_v, ksize_v, go);
 #undef FAST
+    }
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }
