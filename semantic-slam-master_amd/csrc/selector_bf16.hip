@@ -8,6 +8,8 @@
 // (3 channel chunks x 9 taps); A rows come from a bf16 copy of the feature map (written by sslam_bn_tokens) through a
 // register-double-buffered LDS stage (272-B rows), B fragments stream from L2 in fragment order, 4 k-steps ahead.
 // With 16x the matrix rate the kernel is bound by the A-tile traffic (9 L1/L2 re-reads of 256 B per row and stage).
+#include <algorithm>
+
 #include "common.h"
 
 typedef __bf16 bf16;
@@ -156,6 +158,180 @@ __global__ __launch_bounds__(64 * WM * WN) void selector_bf16_kernel(const bf16 
     }
 }
 
+// ---- halo form (hs = 256) ---------------------------------------------------------------------------------------------
+// The stage-per-tap kernel above re-reads every 256-row A tile nine times from L1/L2 (once per tap): 3.3 GB of the 7 GB it
+// moves into the CUs per 613 frames, at the ~8 TB/s that per-lane 16-byte loads sustain from L2.  Here a workgroup loads,
+// once per 64-channel chunk, the rows of its 256 cells PLUS the halo the nine taps reach, and the taps become nine row
+// offsets into that LDS image.  The image lives in PADDED coordinates: a frame is (G + 2) rows of (G + 1) cells - one zero
+// row above and below, one zero column on the right - so that a tap that leaves the grid lands on a zero row by
+// construction: no per-tap validity masks.  Padded index of cell (f, y, x): f * (G+2)(G+1) + (y+1)(G+1) + x.
+//   - 8 waves = 2 (rows) x 4 (columns), wave tile 128 x 64 as above; 36 k-steps per chunk, 6 chunks: 6 barriers, not 27;
+//   - image rows are 144 B (128 B of channels + 16 B pad: consecutive rows rotate by 4 banks mod 64 - 16 lanes cover all 64);
+//   - B fragments stream from L2 exactly as above (same packed weights, same ring).
+constexpr int HC = 64;                   // channels per chunk
+constexpr int HROW = HC * 2 + 16;        // bytes per image row
+constexpr int HKS = HC / 16;             // k-steps per (chunk, tap)
+constexpr int HRING = 4;
+
+template <int NP>                        // 16-byte pieces per thread and chunk: the image has NP * 64 rows
+__global__ __launch_bounds__(512) void selector_bf16_halo_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
+                                                                  const bf16 *__restrict__ w1p, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  float *__restrict__ sal, int n_tiles) {
+    constexpr int WN = 4, MI = 4, BM = 256, HS = 256, NSLAB = HS / 64, NTH = 512;
+    constexpr int IMG = NP * 64 * HROW;                        // bytes per image buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    int tile;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+    }
+    const int m0 = tile * BM;
+    auto padded = [&](int m) {
+        const int f = m / cells, c = m - f * cells, y = c / G, x = c - y * G;
+        return f * P + (y + 1) * G1 + x;
+    };
+    const int p_lo = padded(m0) - (G + 2);                    // first padded row of the image (may be negative: zeros)
+
+    // loader: piece i of this thread is 16 B (8 channels) `part` of image row tid / 8 + 64 i.  Source row decoded once;
+    // rows outside the grid (padding, other side of the sequence ends) get an offset beyond the descriptor: the load returns 0.
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 2u)), 0x00020000);
+    const int part = tid & 7;
+    int a_voff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int pr = p_lo + (tid >> 3) + 64 * i;
+        int off = -16;                                        // 0xfffffff0: out of range
+        if (pr >= 0) {
+            const int f = pr / P, q = pr - f * P, yy = q / G1, xx = q - yy * G1;
+            const long long m = (long long)f * cells + (yy - 1) * G + xx;
+            if (yy >= 1 && yy <= G && xx < G && m < n_rows) off = (int)((unsigned)m * (SSLAM_C * 2u) + part * 16u);
+        }
+        a_voff[i] = off;
+    }
+    u32x4 ra[NP];
+#define H_LOAD(C)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NP; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[i], (C) * (HC * 2), 0);
+#define H_STORE(BUF)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NP; i++)                                                           \
+        *reinterpret_cast<u32x4 *>(hsm + (BUF) * IMG + ((tid >> 3) + 64 * i) * HROW + part * 16) = ra[i];
+
+    // A fragment of lane (r, h), row tile mi: image row of its cell, + the tap's row offset, + 32 ks + 16 h bytes
+    int a_off[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        const int m = min(m0 + wm * 128 + mi * 32 + r, n_rows - 1);
+        a_off[mi] = (padded(m) - p_lo) * HROW + 16 * h;
+    }
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+        const float bv = b1[wn * 64 + ni * 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
+    }
+    // B fragments: packed [stage = chunk128 * 9 + tap][ks8][n/32][64 lanes][8]; chunk c (64 channels), tap t, k-step k4 is
+    // stage (c >> 1) * 9 + t, ks8 = (c & 1) * 4 + k4
+    constexpr int GSTR = (HS / 32) * 64 * 16;          // bytes per global k-step
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(w1p), 0, 9 * SSLAM_C * HS * 2, 0x00020000);
+    const int b_voff = ((wn * 2) * 64 + lane) * 16;
+    auto chunk_base = [](int c) { return (((c >> 1) * 9) * 8 + (c & 1) * 4) * GSTR; };
+    bf16x8 bq[HRING][2];
+#pragma unroll
+    for (int i = 0; i < HRING; i++) {                   // steps 0..3: chunk 0, tap 0, k4 = i
+        bq[i][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, i * GSTR, 0));
+        bq[i][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, i * GSTR + 1024, 0));
+    }
+    H_LOAD(0);
+    H_STORE(0);
+    __syncthreads();
+    constexpr int NCH = SSLAM_C / HC;
+    // Software pipeline, fixed by scheduling barriers (left alone, the scheduler sinks every load next to its use: the ring
+    // collapses to one step and each MFMA group waits for an LDS round trip): per k-step
+    //     [A fragments of step s + 1 : 4 ds_read_b128]  [8 MFMAs of step s]  [B refill of the slot just consumed <- step s + HRING]
+#pragma unroll 1
+    for (int c = 0; c < NCH; c++) {
+        if (c + 1 < NCH) H_LOAD(c + 1);
+        const unsigned char *img = hsm + (c & 1) * IMG;
+        const int base_c = chunk_base(c), base_n = chunk_base(min(c + 1, NCH - 1));
+        bf16x8 a[2][MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) a[0][mi] = *reinterpret_cast<const bf16x8 *>(img + a_off[mi] - (G1 + 1) * HROW);   // tap 0, k4 0
+#pragma unroll
+        for (int st = 0; st < 9 * HKS; st++) {
+            const int cur = st & 1, slot = st % HRING;
+            if (st + 1 < 9 * HKS) {
+                const int tap = (st + 1) / HKS, k4 = (st + 1) % HKS;
+                const int toff = ((tap / 3 - 1) * G1 + (tap % 3 - 1)) * HROW + k4 * 32;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) a[cur ^ 1][mi] = *reinterpret_cast<const bf16x8 *>(img + a_off[mi] + toff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], bq[slot][0], acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], bq[slot][1], acc[mi][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // refill: step + HRING, in this chunk or the next (clamped at the very end: a redundant reload)
+                const int nxt = st + HRING;
+                const int goff = nxt < 9 * HKS ? base_c + ((nxt / HKS) * 8 + nxt % HKS) * GSTR
+                                               : base_n + (((nxt - 9 * HKS) / HKS) * 8 + (nxt - 9 * HKS) % HKS) * GSTR;
+                bq[slot][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, goff, 0));
+                bq[slot][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, goff + 1024, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 1 < NCH) H_STORE((c + 1) & 1);
+        __syncthreads();
+    }
+#undef H_LOAD
+#undef H_STORE
+    // epilogue identical to the exact kernel: ReLU, 1x1 conv tree, sigmoid (fp32)
+    float *red = reinterpret_cast<float *>(hsm);
+    {
+        const float w2a = w2[wn * 64 + r], w2b = w2[wn * 64 + 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[mi][0][e] > 0.0f ? acc[mi][0][e] : 0.0f;
+                const float h1 = acc[mi][1][e] > 0.0f ? acc[mi][1][e] : 0.0f;
+                const float t = bfly32(h0 * w2a + h1 * w2b);
+                if (r == 0) red[wn * BM + wm * 32 * MI + mi * 32 + crow(e, h)] = t;
+            }
+    }
+    __syncthreads();
+    for (int t = tid; t < BM; t += NTH) {
+        const long long m = (long long)m0 + t;
+        if (m < n_rows) {
+            float logit = b2[0];
+#pragma unroll
+            for (int sl = 0; sl < NSLAB; sl++) logit = logit + red[sl * BM + t];
+            sal[m] = sslam_sigmoid(logit);
+        }
+    }
+}
+
+// image rows the halo kernel needs for a G x G grid (exact maximum over tile positions within one period of the pattern)
+int halo_rows(int G, long long n_rows) {
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    auto padded = [&](long long m) { const long long f = m / cells, c = m - f * cells, y = c / G, x = c - y * G; return f * P + (y + 1) * G1 + x; };
+    long long worst = 0;
+    const long long n_tiles = (n_rows + 255) / 256, scan = std::min<long long>(n_tiles, 4LL * cells);   // the pattern repeats every lcm(256, cells) rows
+    for (long long t = 0; t < scan; t++) {
+        const long long m0 = t * 256, m1 = std::min<long long>(m0 + 255, n_rows - 1);
+        worst = std::max(worst, padded(m1) - padded(m0) + 2 * (G + 2) + 1);
+    }
+    return (int)worst;
+}
+
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (bf16)v); }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ in, bf16 *__restrict__ out, long long n8) {
@@ -209,6 +385,27 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
     const long long rows = (long long)n_frames * G * G;
     if (rows * (long long)(SSLAM_C * 2) > 0xffffffffLL) return SSLAM_E_UNSUPPORTED;   // one buffer descriptor spans the bf16 feature map
     hipStream_t st = (hipStream_t)stream;
+    if (hs == 256 && !getenv("SSLAM_CONVBF_NO_HALO")) {
+        const int np = std::max(5, (halo_rows(G, rows) + 63) / 64);      // instantiated for 5..10 x 64 image rows
+        if (np <= 10 && rows < (1LL << 31) / 2) {
+            const int n_tiles = (int)((rows + 255) / 256);
+            const size_t lds = (size_t)2 * np * 64 * HROW;
+#define HALO(NP_)                                                                                                            \
+    hipLaunchKernelGGL((selector_bf16_halo_kernel<NP_>), dim3(n_tiles), dim3(512), lds, st, (const bf16 *)feat_bf16, (int)rows, G, \
+                       (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles)
+            switch (np) {
+                case 10: HALO(10); break;
+                case 9: HALO(9); break;
+                case 8: HALO(8); break;
+                case 7: HALO(7); break;
+                case 6: HALO(6); break;
+                default: HALO(5); break;
+            }
+#undef HALO
+            SSLAM_CHECK_LAUNCH();
+            return SSLAM_OK;
+        }
+    }
     if (hs == 256) {
         static const int variant = [] { const char *e = getenv("SSLAM_CONVBF_VARIANT"); return e ? atoi(e) : 2; }();   // measured: 0: 1.08 ms, 1: 1.28 ms, 2: 0.96 ms / 613 frames
         if (variant == 1) {
