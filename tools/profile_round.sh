@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 RX='selector_saliency|gather_refine|sim_argmax|bn_tokens|preprocess|select_keypoints|intensity_kernel|match_finalize|refine_bf16|selector_bf16|keys_decode'
-VRX='gemm_rt_kernel|attn_kernel|im2patch|prefix_rows|ln_rows'
+VRX='gemm_rt_kernel|mlp_fused_kernel|attn_kernel|im2patch|prefix_rows|ln_rows'
 BENCH="$ROOT/bench.py --steps 5 --warmup 2"
 VIT="$ROOT/tools/bench_vit.py 448 82"
 
