@@ -349,7 +349,7 @@ def main():
                                    f"{K} keypoints, extract once + {n - 1} consecutive-pair matches, all-fp32 exact mode",
                        "vit": "A1 (third-party timm ViT) not in the timed region: tokens are an input (SURVEY 8f-1)",
                        "parallelism": f"frame-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "selector_saliency_kernel (A3 conv3x3 implicit GEMM, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": "selector_saliency_halo_kernel (A3 conv3x3 implicit GEMM, fp32 MFMA; the stage form selector_saliency_kernel on grids whose halo image does not fit)",
                          "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": n * cells * 384 * 4 + n * cells * 4 + 9 * 384 * pipe.selector.hidden * 4,

@@ -262,6 +262,195 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 #undef LOAD_STAGE
 #undef STORE_STAGE
 
+// ---- halo form (hs = 256, throughput shape) ------------------------------------------------------------------------------
+// Same arithmetic, same k order (stage = chunk * 9 + tap), same B stream as selector_saliency_kernel<2, 4, 2, true>; what
+// changes is how the A rows reach LDS.  The stage form stages the 128-row tile once per (chunk, tap): 108 times, each with
+// two loads, eight selects, two LDS stores per thread and a barrier.  Here a workgroup loads, once per 32-channel chunk, its
+// 128 cells PLUS the halo the nine taps reach into an LDS image in ZERO-PADDED coordinates - a frame is (G + 2) rows of
+// (G + 1) cells: one zero row above and below, one zero column on the right; padded index of (f, y, x) =
+// f (G+2)(G+1) + (y+1)(G+1) + x - so a tap that leaves the grid lands on a zero row (same value the stage form multiplies
+// through: +-0 products do not change a sum that starts from the bias... they add +0.0, which is exact) and the nine
+// taps are nine row offsets: 12 staging passes and 12 barriers instead of 108, no validity masks.
+constexpr int HIMG_ROWS = 256;                  // 512 threads x 2 items of 8 floats / 4 items per row
+constexpr int HIMG_FLOATS = HIMG_ROWS * LDT;    // 36 864 B per buffer; two buffers -> two workgroups per CU (147 KB)
+
+__global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const float *__restrict__ feat, int n_rows, int G,
+                                                                         const float *__restrict__ w1p, const float *__restrict__ b1,
+                                                                         const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                         float *__restrict__ sal, int n_tiles) {
+    constexpr int WN = 4, NI = 2, MI = 2, BM = 128, HS = 256, NSLAB = 4;
+    extern __shared__ __attribute__((aligned(16))) float hsmem[];      // 2 x HIMG_FLOATS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    int tile;
+    {
+        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
+        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+    }
+    const int m0 = tile * BM;
+    auto padded = [&](int m) {
+        const int f = m / cells, c = m - f * cells, y = c / G, x = c - y * G;
+        return f * P + (y + 1) * G1 + x;
+    };
+    const int p_lo = padded(m0) - (G + 2);
+
+    // loader: item i of this thread = 8 floats (k-group `kq` of the chunk) of image row (tid >> 2) + 128 i.  Rows outside the
+    // grid get an offset beyond the descriptor (the range check ignores the scalar chunk offset): the loads return zeros.
+    const __amdgpu_buffer_rsrc_t frs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 4u)), 0x00020000);
+    const int kq = tid & 3;
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int pr = p_lo + (tid >> 2) + 128 * i;
+        int off = -32;
+        if (pr >= 0) {
+            const int f = pr / P, q = pr - f * P, yy = q / G1, xx = q - yy * G1;
+            const long long m = (long long)f * cells + (yy - 1) * G + xx;
+            if (yy >= 1 && yy <= G && xx < G && m < n_rows) off = (int)((unsigned)m * (SSLAM_C * 4u) + kq * 32u);
+        }
+        a_voff[i] = off;
+    }
+    float4 ra_lo, ra_hi;
+#define HL(I, C)                                                                                                   \
+    {                                                                                                              \
+        ra_lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[I], (C) * (BK * 4), 0));      \
+        ra_hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[I], (C) * (BK * 4) + 16, 0)); \
+    }
+#define HS_(I, BUF)                                                                                                \
+    {                                                                                                              \
+        float4 ev, od;                                                                                             \
+        kp8_split(ra_lo, ra_hi, ev, od);                                                                           \
+        float *d = hsmem + (BUF) * HIMG_FLOATS + ((tid >> 2) + 128 * (I)) * LDT + kq * 8;                          \
+        *reinterpret_cast<float4 *>(d) = ev;                                                                       \
+        *reinterpret_cast<float4 *>(d + 4) = od;                                                                   \
+    }
+
+    // A fragment rows of this lane: image row of its cell (floats), + 4 h
+    int a_base[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        const int m = min(m0 + wm * 64 + mi * 32 + r, n_rows - 1);
+        a_base[mi] = (padded(m) - p_lo) * LDT + 4 * h;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+        const float bv = b1[wn * 64 + ni * 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
+    }
+    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 64 + r) * 2 + h);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w1p), 0, 9 * SSLAM_C * HS * 4, 0x00020000);
+    const int b_voff = ((wn * 64 + r) * 2 + h) * 16;
+    f32x4 bq[BK / 8][NI];
+#pragma unroll
+    for (int g = 0; g < BK / 8; g++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) bq[g][ni] = bsrc[((long long)g * HS + ni * 32) * 2];
+
+    HL(0, 0);
+    HS_(0, 0);
+    HL(1, 0);
+    HS_(1, 0);
+    __syncthreads();
+    int tap = 0, dy = -1, dx = -1, chunk = 0;
+    for (int s = 0; s < NSTAGE; s++) {
+        // next chunk's image: item 0 fetched during tap 0 and stored after tap 3, item 1 fetched then and stored after tap 8
+        if (chunk + 1 < NCHUNK) {
+            if (tap == 0) HL(0, chunk + 1);
+            if (tap == 4) {
+                HS_(0, (chunk + 1) & 1);
+                HL(1, chunk + 1);
+            }
+        }
+        const float *img = hsmem + (chunk & 1) * HIMG_FLOATS + (dy * G1 + dx) * LDT;
+        const float *A0 = img + a_base[0], *A1 = img + a_base[1];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(A0 + 8 * g);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(A1 + 8 * g);
+            f32x4 b[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) b[ni] = bq[g][ni];
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) {
+                    acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
+                    acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
+                }
+            if (s + 1 < NSTAGE && (g == BK / 16 - 1 || g == BK / 8 - 1)) {
+#pragma unroll
+                for (int gg = g + 1 - BK / 16; gg <= g; gg++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++)
+                        bq[gg][ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            wrs, b_voff, (((s + 1) * (BK / 8) + gg) * HS + ni * 32) * 32, 0));
+            }
+            if (g == BK / 16 - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        tap++; dx++;
+        if (dx == 2) { dx = -1; dy++; }
+        if (tap == 9) {
+            if (chunk + 1 < NCHUNK) HS_(1, (chunk + 1) & 1);
+            __syncthreads();
+            tap = 0; dy = -1; chunk++;
+        }
+    }
+#undef HL
+#undef HS_
+    // epilogue: identical to the stage form (ReLU, 1x1 conv tree, sigmoid)
+    __syncthreads();
+    float *red = hsmem;
+#pragma unroll
+    for (int sl = 0; sl < NI / 2; sl++) {
+        const int slab = wn * (NI / 2) + sl;
+        const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
+                const float h1 = acc[mi][2 * sl + 1][e] > 0.0f ? acc[mi][2 * sl + 1][e] : 0.0f;
+                const float q = h0 * w2a + h1 * w2b;
+                const float t = bfly32(q);
+                if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+            }
+    }
+    __syncthreads();
+    for (int t = tid; t < BM; t += 512) {
+        const long long m = (long long)m0 + t;
+        if (m < n_rows) {
+            float logit = b2[0];
+#pragma unroll
+            for (int sb = 0; sb < NSLAB; sb++) logit = logit + red[sb * BM + t];
+            sal[m] = sslam_sigmoid(logit);
+        }
+    }
+}
+
+// image rows the halo form needs (exact maximum over the tile positions of one period)
+int halo_rows128(int G, long long n_rows) {
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    auto padded = [&](long long m) { const long long f = m / cells, c = m - f * cells, y = c / G, x = c - y * G; return f * P + (y + 1) * G1 + x; };
+    long long worst = 0;
+    const long long n_tiles = (n_rows + 127) / 128, scan = n_tiles < 4LL * cells ? n_tiles : 4LL * cells;
+    for (long long t = 0; t < scan; t++) {
+        const long long m0 = t * 128, m1 = m0 + 127 < n_rows - 1 ? m0 + 127 : n_rows - 1;
+        const long long need = padded(m1) - padded(m0) + 2 * (G + 2) + 1;
+        worst = need > worst ? need : worst;
+    }
+    return (int)worst;
+}
+
 template <int WM, int WN, int NI, bool BD, int MI = 2>
 void launch(const float *feat, long long rows, int G, const float *w1p, const float *b1, const float *w2, const float *b2,
             float *sal, hipStream_t st) {
@@ -289,6 +478,10 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     const long long lat_rows = lat_env ? atoll(lat_env) : 128 * 1800;  // measured cross-over: ~400 frames at G = 28 (6.25 vs 6.10 ms at 613)
     if (hs == 256 && rows <= lat_rows) {
         launch<1, 8, 1, true, 1>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
+    } else if (hs == 256 && variant == 2 && !getenv("SSLAM_CONV_NO_HALO") && halo_rows128(G, rows) <= HIMG_ROWS) {
+        const int n_tiles = (int)((rows + 127) / 128);
+        hipLaunchKernelGGL(selector_saliency_halo_kernel, dim3(n_tiles), dim3(512), 2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G,
+                           w1_packed, b1, w2, b2, sal, n_tiles);
     } else if (hs == 256) {
         switch (variant) {
             case 0: launch<2, 4, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;
