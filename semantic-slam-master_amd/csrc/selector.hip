@@ -437,6 +437,157 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
     }
 }
 
+// ---- latency form 2 (hs = 256, few frames): halo image + the hidden channels split over TWO workgroups ------------------
+// One frame is 25 tiles of 32 cells; the first latency form gives each tile one workgroup of 8 waves (two per SIMD: 2 x 16 MFMAs
+// per stage and SIMD, 108 stages, a barrier each).  Here a tile has two workgroups of 4 waves - 128 hidden channels each, one
+// wave per SIMD, 16 MFMAs per stage - on the halo image (12 barriers): the chain per output is the same single fma chain.  The
+// 1x1 conv's canonical tree (in-lane pair per 64-column slab, 32-lane butterfly, slabs IN ORDER) crosses the two workgroups only
+// at its last level: each writes its two slab totals per cell to `part` (cells x 4), `saliency_finish_kernel` adds them in order.
+template <int NP>      // 8-float items per thread and chunk: the image has NP * 64 rows
+__global__ __launch_bounds__(256) void selector_saliency_lat2_kernel(const float *__restrict__ feat, int n_rows, int G,
+                                                                      const float *__restrict__ w1p, const float *__restrict__ b1,
+                                                                      const float *__restrict__ w2, float *__restrict__ part) {
+    constexpr int HS = 256, BM = 32;
+    constexpr int IMG_FLOATS = NP * 64 * LDT;
+    extern __shared__ __attribute__((aligned(16))) float hsmem[];      // 2 x IMG_FLOATS; reused by the epilogue
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int half = blockIdx.x & 1, tile = blockIdx.x >> 1;
+    const int col0 = half * 128 + wn * 32;                             // this wave's 32 hidden channels
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    const int m0 = tile * BM;
+    auto padded = [&](int m) {
+        const int f = m / cells, c = m - f * cells, y = c / G, x = c - y * G;
+        return f * P + (y + 1) * G1 + x;
+    };
+    const int p_lo = padded(m0) - (G + 2);
+    const __amdgpu_buffer_rsrc_t frs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 4u)), 0x00020000);
+    const int kq = tid & 3;
+    int a_voff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int pr = p_lo + (tid >> 2) + 64 * i;
+        int off = -32;
+        if (pr >= 0) {
+            const int f = pr / P, q = pr - f * P, yy = q / G1, xx = q - yy * G1;
+            const long long m = (long long)f * cells + (yy - 1) * G + xx;
+            if (yy >= 1 && yy <= G && xx < G && m < n_rows) off = (int)((unsigned)m * (SSLAM_C * 4u) + kq * 32u);
+        }
+        a_voff[i] = off;
+    }
+    float4 ra_lo[NP], ra_hi[NP];
+#define LL(C)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NP; i++) {                                                                   \
+        ra_lo[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[i], (C) * (BK * 4), 0));      \
+        ra_hi[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(frs, a_voff[i], (C) * (BK * 4) + 16, 0)); \
+    }
+#define LS(BUF)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NP; i++) {                                                                   \
+        float4 ev, od;                                                                                                 \
+        kp8_split(ra_lo[i], ra_hi[i], ev, od);                                                                         \
+        float *d = hsmem + (BUF) * IMG_FLOATS + ((tid >> 2) + 64 * i) * LDT + kq * 8;                                  \
+        *reinterpret_cast<float4 *>(d) = ev;                                                                           \
+        *reinterpret_cast<float4 *>(d + 4) = od;                                                                       \
+    }
+    const int a_base = (padded(min(m0 + r, n_rows - 1)) - p_lo) * LDT + 4 * h;
+
+    f32x16 acc;
+    {
+        const float bv = b1[col0 + r];
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = bv;
+    }
+    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((col0 + r) * 2 + h);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w1p), 0, 9 * SSLAM_C * HS * 4, 0x00020000);
+    const int b_voff = ((col0 + r) * 2 + h) * 16;
+    // ring of TWO stages (8 k-groups): with one wave per SIMD a fragment must be requested >= one L2 round trip ahead, and a
+    // stage is only 1 024 matrix cycles here
+    f32x4 bq[2][BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; g++) {
+        bq[0][g] = bsrc[((long long)g * HS) * 2];
+        bq[1][g] = bsrc[((long long)(BK / 8 + g) * HS) * 2];
+    }
+    LL(0);
+    LS(0);
+    __syncthreads();
+    int tap = 0, dy = -1, dx = -1, chunk = 0;
+#pragma unroll 2
+    for (int s = 0; s < NSTAGE; s++) {
+        if (tap == 0 && chunk + 1 < NCHUNK) LL(chunk + 1);
+        const float *A = hsmem + (chunk & 1) * IMG_FLOATS + (dy * G1 + dx) * LDT + a_base;
+        f32x4 a[BK / 8];
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++) a[g] = *reinterpret_cast<const f32x4 *>(A + 8 * g);
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) acc = mfma32(a[g][st], bq[s & 1][g][st], acc);
+            const int sn = min(s + 2, NSTAGE - 1);                      // refill with the stage after next (clamped: a redundant reload)
+            bq[s & 1][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, ((sn * (BK / 8) + g) * HS) * 32, 0));
+        }
+        tap++; dx++;
+        if (dx == 2) { dx = -1; dy++; }
+        if (tap == 9) {
+            if (chunk + 1 < NCHUNK) LS((chunk + 1) & 1);
+            __syncthreads();
+            tap = 0; dy = -1; chunk++;
+        }
+    }
+#undef LL
+#undef LS
+    // epilogue: waves (0, 1) are the 64-column slab 2 half, waves (2, 3) slab 2 half + 1; the odd wave hands its products over
+    // through LDS, the even wave forms q = h0 * w2a + h1 * w2b exactly as the in-lane form does and reduces it (butterfly)
+    __syncthreads();
+    float *xch = hsmem;                        // [2 slabs][16 e][64 lanes]
+    const int sl = wn >> 1;
+    const float w2v = w2[col0 + r];
+    if (wn & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float h1 = acc[e] > 0.0f ? acc[e] : 0.0f;
+            xch[(sl * 16 + e) * 64 + lane] = h1 * w2v;
+        }
+    }
+    __syncthreads();
+    if (!(wn & 1)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float h0 = acc[e] > 0.0f ? acc[e] : 0.0f;
+            const float q = h0 * w2v + xch[(sl * 16 + e) * 64 + lane];
+            const float t = bfly32(q);
+            const int m = m0 + crow(e, h);
+            if (r == 0 && m < n_rows) part[(long long)m * 4 + half * 2 + sl] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void saliency_finish_kernel(const float *__restrict__ part, const float *__restrict__ b2, int n_rows,
+                                                               float *__restrict__ sal) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_rows) return;
+    const f32x4 p4 = *reinterpret_cast<const f32x4 *>(part + (long long)m * 4);
+    float logit = b2[0];
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) logit = logit + p4[sb];
+    sal[m] = sslam_sigmoid(logit);
+}
+
+// image rows a 32-cell tile needs (exact maximum over the tile positions of one period)
+int halo_rows32(int G, long long n_rows) {
+    const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
+    auto padded = [&](long long m) { const long long f = m / cells, c = m - f * cells, y = c / G, x = c - y * G; return f * P + (y + 1) * G1 + x; };
+    long long worst = 0;
+    const long long n_tiles = (n_rows + 31) / 32, scan = n_tiles < 4LL * cells ? n_tiles : 4LL * cells;
+    for (long long t = 0; t < scan; t++) {
+        const long long m0 = t * 32, m1 = m0 + 31 < n_rows - 1 ? m0 + 31 : n_rows - 1;
+        const long long need = padded(m1) - padded(m0) + 2 * (G + 2) + 1;
+        worst = need > worst ? need : worst;
+    }
+    return (int)worst;
+}
+
 // image rows the halo form needs (exact maximum over the tile positions of one period)
 int halo_rows128(int G, long long n_rows) {
     const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
@@ -476,6 +627,38 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     // 0.47 ms for one frame; still ahead at 256 frames: 2.90 vs 3.02 ms)
     const char *lat_env = getenv("SSLAM_CONV_LATENCY_ROWS");          // 0 forces the throughput form (tests, A/B timing)
     const long long lat_rows = lat_env ? atoll(lat_env) : 128 * 1800;  // measured cross-over: ~400 frames at G = 28 (6.25 vs 6.10 ms at 613)
+    // latency form 2 up to this many rows (env SSLAM_CONV_LAT2_ROWS; 0 disables).  Measured (tools/conv_forms.py, G = 28): 1 / 4 / 8
+    // / 16 frames: 0.070 / 0.077 / 0.129 / 0.247 ms against 0.123 / 0.123 / 0.129 / 0.224 ms for the 8-wave latency form - one
+    // wave per SIMD stops paying once the 50 workgroups per frame fill the chip (6 frames)
+    const char *l2_env = getenv("SSLAM_CONV_LAT2_ROWS");
+    const long long lat2_rows = l2_env ? atoll(l2_env) : 32 * 25 * 6;
+    if (hs == 256 && rows <= lat2_rows && rows <= lat_rows) {
+        const int np = (halo_rows32(G, rows) + 63) / 64;
+        if (np <= 6) {
+            float *part = nullptr;
+            if (hipMallocAsync((void **)&part, (size_t)rows * 4 * sizeof(float), st) != hipSuccess) return SSLAM_E_LAUNCH;   // stream-ordered scratch
+            const int n_tiles = (int)((rows + 31) / 32);
+#define LAT2(NP_)                                                                                                              \
+    hipLaunchKernelGGL((selector_saliency_lat2_kernel<NP_>), dim3(2 * n_tiles), dim3(256), 2 * NP_ * 64 * LDT * sizeof(float), st, feat, \
+                       (int)rows, G, w1_packed, b1, w2, part)
+            switch (np) {
+                case 6: LAT2(6); break;
+                case 5: LAT2(5); break;
+                case 4: LAT2(4); break;
+                case 3: LAT2(3); break;
+                default: LAT2(2); break;
+            }
+#undef LAT2
+            bool ok = hipGetLastError() == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(saliency_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, b2, (int)rows, sal);
+                ok = hipGetLastError() == hipSuccess;
+            }
+            (void)hipFreeAsync(part, st);
+            g_sslam_launches += 2;
+            return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
+        }
+    }
     if (hs == 256 && rows <= lat_rows) {
         launch<1, 8, 1, true, 1>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
     } else if (hs == 256 && variant == 2 && !getenv("SSLAM_CONV_NO_HALO") && halo_rows128(G, rows) <= HIMG_ROWS) {
