@@ -8,9 +8,11 @@
  *
  * Conventions (all entries):
  *   - every pointer is a CALLER-OWNED DEVICE pointer unless the name ends in _host; the library never copies to
- *     the host and allocates nothing, with ONE documented exception: the batched form of sslam_sim_argmax takes
- *     n_pairs*n2*8 bytes of stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`, released on every
- *     return path); pass SSLAM_M1_VARIANT=1 for the scratch-free form;
+ *     the host and allocates nothing, with TWO documented exceptions, both stream-ordered scratch (hipMallocAsync /
+ *     hipFreeAsync on `stream`, released on every return path): the batched form of sslam_sim_argmax takes
+ *     n_pairs*n2*8 bytes (SSLAM_M1_VARIANT=1 selects the scratch-free form), and sslam_selector_saliency on at most
+ *     six 28x28 frames (its two-workgroups-per-tile latency form) takes 16 bytes per cell (SSLAM_CONV_LAT2_ROWS=0
+ *     selects the scratch-free forms);
  *   - `stream` is a hipStream_t passed as void* (PyTorch: torch.cuda.current_stream().cuda_stream); calls only
  *     enqueue work - no synchronisation, no host read-back;
  *   - return value: SSLAM_OK or a negative SSLAM_E_* code; launch failures are reported via hipGetLastError;
@@ -78,7 +80,9 @@ int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int
 
 /* ---- A3: saliency CNN.  Replaces KeypointSelector.forward, keypoint_selector.py:45-67
  * (conv3x3 384->hs + ReLU + conv1x1 hs->1 + sigmoid).  feat (n_frames, G, G, 384) NHWC; w1_packed from
- * sslam_pack_conv3x3_host; b1 (hs), w2 (hs), b2 (1); hs in {128, 256}.  sal (n_frames, G, G). */
+ * sslam_pack_conv3x3_host; b1 (hs), w2 (hs), b2 (1); hs in {128, 256}.  sal (n_frames, G, G).
+ * Four launch shapes, chosen by size, all bit-identical (same fma chain per output; csrc/selector.hip): the halo
+ * and the stage form of the 128-row throughput kernel, and two latency forms for few frames. */
 int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
                             const float *w2, const float *b2, int hs, float *sal, void *stream);
 
