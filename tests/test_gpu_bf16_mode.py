@@ -74,7 +74,7 @@ def test_bn_tokens_bf16_copy(T, hip):
     np.testing.assert_array_equal(fb.float().cpu().numpy().view(np.uint32), bf16_round(want).view(np.uint32))
 
 
-@pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (28, 2, 128), (5, 2, 256)])
+@pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256), (60, 2, 256), (40, 3, 256)])
 def test_selector_saliency_bf16(T, hip, grid, frames, hidden):
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
     feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
