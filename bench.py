@@ -263,7 +263,7 @@ def main():
         del tok_buf
         vit_tf = n * vit_flop / (vit_ms * 1e-3) / 1e12
         vit_leg = {"value": round(n / dtv, 2), "unit": "frames/s", "ms_per_step": round(dtv * 1e3, 3),
-                   "roofline": {"bound": "mfma", "kernel": "A0 + sslam_vit_forward (61 launches per 64-frame chunk: row-tile GEMMs, attention)",
+                   "roofline": {"bound": "mfma", "kernel": "A0 + sslam_vit_forward (52 launches per 82-frame chunk: row-tile GEMMs, attention, fused MLP)",
                                 "achieved": round(vit_tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(vit_tf / 2500.0, 4),
                                 "launch_ms": round(vit_ms, 3), "flop_per_launch": int(n * vit_flop),
                                 "note": "dense bf16 MFMA peak (spec); a pure bf16 MFMA loop on random data sustains ~1.3-1.5 PFLOP/s on this chip (DVFS)"},
