@@ -576,6 +576,9 @@ __global__ __launch_bounds__(256) void saliency_finish_kernel(const float *__res
 
 // image rows a 32-cell tile needs (exact maximum over the tile positions of one period)
 int halo_rows32(int G, long long n_rows) {
+    thread_local int c_G = 0, c_val = 0;           // the scan below is ~3 000 iterations at 613 frames: remember the last answer
+    thread_local long long c_rows = 0;
+    if (G == c_G && n_rows == c_rows) return c_val;
     const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
     auto padded = [&](long long m) { const long long f = m / cells, c = m - f * cells, y = c / G, x = c - y * G; return f * P + (y + 1) * G1 + x; };
     long long worst = 0;
@@ -585,11 +588,15 @@ int halo_rows32(int G, long long n_rows) {
         const long long need = padded(m1) - padded(m0) + 2 * (G + 2) + 1;
         worst = need > worst ? need : worst;
     }
+    c_G = G, c_rows = n_rows, c_val = (int)worst;
     return (int)worst;
 }
 
 // image rows the halo form needs (exact maximum over the tile positions of one period)
 int halo_rows128(int G, long long n_rows) {
+    thread_local int c_G = 0, c_val = 0;           // the scan below is ~3 000 iterations at 613 frames: remember the last answer
+    thread_local long long c_rows = 0;
+    if (G == c_G && n_rows == c_rows) return c_val;
     const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
     auto padded = [&](long long m) { const long long f = m / cells, c = m - f * cells, y = c / G, x = c - y * G; return f * P + (y + 1) * G1 + x; };
     long long worst = 0;
@@ -599,6 +606,7 @@ int halo_rows128(int G, long long n_rows) {
         const long long need = padded(m1) - padded(m0) + 2 * (G + 2) + 1;
         worst = need > worst ? need : worst;
     }
+    c_G = G, c_rows = n_rows, c_val = (int)worst;
     return (int)worst;
 }
 
