@@ -158,7 +158,7 @@ class SequencePipeline:
 
     def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None) -> torch.Tensor:
         """A0 + A1: (N, H, W, 3) uint8 -> (N, 5 + G*G, 384) fp32 tokens via the HIP ViT, `vit_chunk` frames at a time.
-        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (82 frames at 448 x 448)."""
+        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (164 frames at 448 x 448)."""
         if self.vit_hip is None:
             raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
         if vit_chunk is None:

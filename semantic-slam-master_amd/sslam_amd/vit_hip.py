@@ -56,10 +56,11 @@ class HipViT:
 
     @staticmethod
     def chunk_frames(size: int) -> int:
-        """Frames per launch group: just under 2 x 253 row tiles of 128 tokens.  The GEMM launches run one workgroup per (row
-        tile, column half) at two per CU and the fused MLP one per row tile, so 506 tiles are whole rounds for all of them
-        (82 frames at 448 x 448: 14.8 k frames/s; 41 frames: 13.6 k; 64 frames = a partial round: 12.8 k)."""
-        return max(1, (506 * 128) // (5 + (size // 16) ** 2))
+        """Frames per launch group: just under 4 x 253 row tiles of 128 tokens.  The GEMM launches run one workgroup per (row
+        tile, column half) at two per CU and the fused MLP one per row tile, so a multiple of 253 tiles is whole rounds for all
+        of them; more rounds per launch amortise the ramp and the uneven tail of every launch (448 x 448: 41 frames = 1 round
+        14.0 k frames/s, 82 = 2 rounds 15.0 k, 164 = 4 rounds 15.2 k, 205: 15.2 k; 64 frames = a partial round: 13.3 k)."""
+        return max(1, (1012 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
         """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group."""
