@@ -274,21 +274,16 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 constexpr int HIMG_ROWS = 256;                  // 512 threads x 2 items of 8 floats / 4 items per row
 constexpr int HIMG_FLOATS = HIMG_ROWS * LDT;    // 36 864 B per buffer; two buffers -> two workgroups per CU (147 KB)
 
-__global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const float *__restrict__ feat, int n_rows, int G,
-                                                                         const float *__restrict__ w1p, const float *__restrict__ b1,
-                                                                         const float *__restrict__ w2, const float *__restrict__ b2,
-                                                                         float *__restrict__ sal, int n_tiles) {
-    constexpr int WN = 4, NI = 2, MI = 2, BM = 128, HS = 256, NSLAB = 4;
-    extern __shared__ __attribute__((aligned(16))) float hsmem[];      // 2 x HIMG_FLOATS
+// One tile of the halo form.  SMALL = false: 128 cells, waves 2 (rows) x 4 (columns), 64 x 64 per wave.  SMALL = true: 32 cells,
+// 8 column waves of 32 x 32 - a quarter of the work, used for the rows BEYOND the last whole round of big tiles (below).
+template <bool SMALL>
+__device__ __forceinline__ void halo_tile(float *hsmem, const float *__restrict__ feat, int n_rows, int G, const float *__restrict__ w1p,
+                                          const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                                          float *__restrict__ sal, const int m0) {
+    constexpr int WN = SMALL ? 8 : 4, NI = SMALL ? 1 : 2, MI = SMALL ? 1 : 2, BM = 32 * MI * (8 / WN), HS = 256, NSLAB = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
-    int tile;
-    {
-        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
-        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
-    }
-    const int m0 = tile * BM;
     auto padded = [&](int m) {
         const int f = m / cells, c = m - f * cells, y = c / G, x = c - y * G;
         return f * P + (y + 1) * G1 + x;
@@ -331,23 +326,23 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
     int a_base[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
-        const int m = min(m0 + wm * 64 + mi * 32 + r, n_rows - 1);
+        const int m = min(m0 + wm * 32 * MI + mi * 32 + r, n_rows - 1);
         a_base[mi] = (padded(m) - p_lo) * LDT + 4 * h;
     }
 
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
-        const float bv = b1[wn * 64 + ni * 32 + r];
+        const float bv = b1[wn * 32 * NI + ni * 32 + r];
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[mi][ni][e] = bv;
     }
-    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 64 + r) * 2 + h);
+    const f32x4 *bsrc = reinterpret_cast<const f32x4 *>(w1p) + ((wn * 32 * NI + r) * 2 + h);
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w1p), 0, 9 * SSLAM_C * HS * 4, 0x00020000);
-    const int b_voff = ((wn * 64 + r) * 2 + h) * 16;
+    const int b_voff = ((wn * 32 * NI + r) * 2 + h) * 16;
     f32x4 bq[BK / 8][NI];
 #pragma unroll
     for (int g = 0; g < BK / 8; g++)
@@ -370,12 +365,13 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
             }
         }
         const float *img = hsmem + (chunk & 1) * HIMG_FLOATS + (dy * G1 + dx) * LDT;
-        const float *A0 = img + a_base[0], *A1 = img + a_base[1];
+        const float *A0 = img + a_base[0], *A1 = img + a_base[MI - 1];
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(A0 + 8 * g);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(A1 + 8 * g);
+            f32x4 a1 = a0;
+            if (MI == 2) a1 = *reinterpret_cast<const f32x4 *>(A1 + 8 * g);
             f32x4 b[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) b[ni] = bq[g][ni];
@@ -384,7 +380,7 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) {
                     acc[0][ni] = mfma32(a0[st], b[ni][st], acc[0][ni]);
-                    acc[1][ni] = mfma32(a1[st], b[ni][st], acc[1][ni]);
+                    if (MI == 2) acc[MI - 1][ni] = mfma32(a1[st], b[ni][st], acc[MI - 1][ni]);
                 }
             if (s + 1 < NSTAGE && (g == BK / 16 - 1 || g == BK / 8 - 1)) {
 #pragma unroll
@@ -410,20 +406,45 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
     // epilogue: identical to the stage form (ReLU, 1x1 conv tree, sigmoid)
     __syncthreads();
     float *red = hsmem;
+    if (!SMALL) {
 #pragma unroll
-    for (int sl = 0; sl < NI / 2; sl++) {
-        const int slab = wn * (NI / 2) + sl;
-        const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
+        for (int sl = 0; sl < NI / 2; sl++) {
+            const int slab = wn * (NI / 2) + sl;
+            const float w2a = w2[slab * 64 + r], w2b = w2[slab * 64 + 32 + r];
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++)
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
+                    const float h1 = acc[mi][NI > 1 ? 2 * sl + 1 : 0][e] > 0.0f ? acc[mi][NI > 1 ? 2 * sl + 1 : 0][e] : 0.0f;
+                    const float q = h0 * w2a + h1 * w2b;
+                    const float t = bfly32(q);
+                    if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+                }
+        }
+    } else {
+        // the two 32-column halves of a 64-column slab belong to waves wn = 2 slab and 2 slab + 1: the odd wave hands its
+        // products over through LDS, the even wave forms q = h0 * w2a + h1 * w2b exactly as the in-lane form does
+        float *xch = hsmem + NSLAB * BM;           // [4 slabs][16 e][64 lanes]
+        const int slab = wn >> 1;
+        const float w2v = w2[wn * 32 + r];
+        if (wn & 1) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float h0 = acc[mi][2 * sl][e] > 0.0f ? acc[mi][2 * sl][e] : 0.0f;
-                const float h1 = acc[mi][2 * sl + 1][e] > 0.0f ? acc[mi][2 * sl + 1][e] : 0.0f;
-                const float q = h0 * w2a + h1 * w2b;
-                const float t = bfly32(q);
-                if (r == 0) red[slab * BM + wm * 64 + mi * 32 + crow(e, h)] = t;
+                const float h1 = acc[0][0][e] > 0.0f ? acc[0][0][e] : 0.0f;
+                xch[(slab * 16 + e) * 64 + lane] = h1 * w2v;
             }
+        }
+        __syncthreads();
+        if (!(wn & 1)) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float h0 = acc[0][0][e] > 0.0f ? acc[0][0][e] : 0.0f;
+                const float q = h0 * w2v + xch[(slab * 16 + e) * 64 + lane];
+                const float t = bfly32(q);
+                if (r == 0) red[slab * BM + crow(e, h)] = t;
+            }
+        }
     }
     __syncthreads();
     for (int t = tid; t < BM; t += 512) {
@@ -434,6 +455,25 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
             for (int sb = 0; sb < NSLAB; sb++) logit = logit + red[sb * BM + t];
             sal[m] = sslam_sigmoid(logit);
         }
+    }
+}
+
+// Grid = n_big tiles of 128 cells (XCD-aware order) followed by the 32-cell tiles of the remaining rows.  A launch is
+// 7.33 rounds of 512 workgroup slots at 613 frames: during whole rounds the matrix pipe is saturated (7.33 x 0.737 ms of MFMA issue
+// = 5.40 of the 5.87 ms the all-big grid took), and the third of a round at the end ran one workgroup per CU at half rate.  With the
+// big tiles cut at the last whole round, the rest is dispatched as quarter-size workgroups that fill every slot.
+__global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const float *__restrict__ feat, int n_rows, int G,
+                                                                         const float *__restrict__ w1p, const float *__restrict__ b1,
+                                                                         const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                         float *__restrict__ sal, int n_big) {
+    extern __shared__ __attribute__((aligned(16))) float hsmem[];      // 2 x HIMG_FLOATS
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        const int q = n_big / 8, rem = n_big % 8, x = b % 8;
+        const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+        halo_tile<false>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, tile * 128);
+    } else {
+        halo_tile<true>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, n_big * 128 + (b - n_big) * 32);
     }
 }
 
@@ -670,9 +710,14 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     if (hs == 256 && rows <= lat_rows) {
         launch<1, 8, 1, true, 1>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
     } else if (hs == 256 && variant == 2 && !getenv("SSLAM_CONV_NO_HALO") && halo_rows128(G, rows) <= HIMG_ROWS) {
+        // big tiles up to the last whole round of 2 workgroups x 256 CUs, 32-cell tiles for the rest (SSLAM_CONV_TAIL: the round size, 0 = all big)
         const int n_tiles = (int)((rows + 127) / 128);
-        hipLaunchKernelGGL(selector_saliency_halo_kernel, dim3(n_tiles), dim3(512), 2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G,
-                           w1_packed, b1, w2, b2, sal, n_tiles);
+        const char *tail_env = getenv("SSLAM_CONV_TAIL");             // round size in tiles (tests use a small one); 0: all big
+        const int round = tail_env ? atoi(tail_env) : 512;
+        const int n_big = round > 0 && n_tiles > round ? n_tiles / round * round : n_tiles;
+        const int n_small = n_big < n_tiles ? (int)((rows - (long long)n_big * 128 + 31) / 32) : 0;
+        hipLaunchKernelGGL(selector_saliency_halo_kernel, dim3(n_big + n_small), dim3(512), 2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G,
+                           w1_packed, b1, w2, b2, sal, n_big);
     } else if (hs == 256) {
         switch (variant) {
             case 0: launch<2, 4, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;

@@ -91,15 +91,18 @@ def _packed_selector(T, hip, sd):
             sd["conv.0.weight"].shape[0])
 
 
-@pytest.mark.parametrize("form", ["latency2", "latency", "throughput", "throughput_stage"])
+@pytest.mark.parametrize("form", ["latency2", "latency", "throughput", "throughput_tail", "throughput_stage"])
 @pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (60, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256)])
 def test_selector_saliency(T, hip, grid, frames, hidden, form, monkeypatch):
     """Every launch shape of the conv, all bit-identical: 32-cell tiles split over two workgroups on the halo image (few
-    frames), 32-row workgroups of 8 waves, 128-row workgroups on the halo image (G = 28) and the stage-per-tap form."""
+    frames), 32-row workgroups of 8 waves, 128-row workgroups on the halo image (G = 28), the same with the last partial round cut into 32-cell tiles, and the
+    stage-per-tap form."""
     monkeypatch.setenv("SSLAM_CONV_LATENCY_ROWS", "0" if form.startswith("throughput") else str(1 << 30))
     monkeypatch.setenv("SSLAM_CONV_LAT2_ROWS", str(1 << 30) if form == "latency2" else "0")
     if form == "throughput_stage":
         monkeypatch.setenv("SSLAM_CONV_NO_HALO", "1")
+    if form == "throughput_tail":
+        monkeypatch.setenv("SSLAM_CONV_TAIL", "4")          # rounds of 4 big tiles: the rest of the rows go to 32-cell tiles
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
     feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
     w1p, b1, w2, b2, hs = _packed_selector(T, hip, sd)
