@@ -173,23 +173,17 @@ constexpr int HROW = HC * 2 + 16;        // bytes per image row
 constexpr int HKS = HC / 16;             // k-steps per (chunk, tap)
 constexpr int HRING = 4;
 
-template <int NP>                        // 16-byte pieces per thread and chunk: the image has NP * 64 rows
-__global__ __launch_bounds__(512) void selector_bf16_halo_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
-                                                                  const bf16 *__restrict__ w1p, const float *__restrict__ b1,
-                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
-                                                                  float *__restrict__ sal, int n_tiles) {
-    constexpr int WN = 4, MI = 4, BM = 256, HS = 256, NSLAB = HS / 64, NTH = 512;
+// One tile: NP = 16-byte pieces per thread and chunk (the image has NP * 64 rows); MI = row tiles of 32 per wave: 4 -> 256-cell
+// tiles, 2 -> 128-cell tiles (half the work; for the rows beyond the last whole round, see the kernel below)
+template <int NP, int MI>
+__device__ __forceinline__ void halo_bf16_tile(unsigned char *hsm, const bf16 *__restrict__ feat, int n_rows, int G,
+                                               const bf16 *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2,
+                                               const float *__restrict__ b2, float *__restrict__ sal, const int m0) {
+    constexpr int WN = 4, BM = 64 * MI, HS = 256, NSLAB = HS / 64, NTH = 512;
     constexpr int IMG = NP * 64 * HROW;                        // bytes per image buffer
-    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int cells = G * G, G1 = G + 1, P = (G + 2) * G1;
-    int tile;
-    {
-        const int b = blockIdx.x, q = n_tiles / 8, rem = n_tiles % 8, x = b % 8;
-        tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
-    }
-    const int m0 = tile * BM;
     auto padded = [&](int m) {
         const int f = m / cells, c = m - f * cells, y = c / G, x = c - y * G;
         return f * P + (y + 1) * G1 + x;
@@ -223,7 +217,7 @@ __global__ __launch_bounds__(512) void selector_bf16_halo_kernel(const bf16 *__r
     int a_off[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
-        const int m = min(m0 + wm * 128 + mi * 32 + r, n_rows - 1);
+        const int m = min(m0 + wm * 32 * MI + mi * 32 + r, n_rows - 1);
         a_off[mi] = (padded(m) - p_lo) * HROW + 16 * h;
     }
 
@@ -319,6 +313,24 @@ __global__ __launch_bounds__(512) void selector_bf16_halo_kernel(const bf16 *__r
     }
 }
 
+// Grid = n_big tiles of 256 cells (XCD-aware order), then 128-cell tiles for the remaining rows: with one workgroup per CU a
+// launch of 7.33 rounds (613 frames) otherwise costs 8 (tools/conv_rounds.py shows the same steps for the exact kernel).
+template <int NP>
+__global__ __launch_bounds__(512) void selector_bf16_halo_kernel(const bf16 *__restrict__ feat, int n_rows, int G,
+                                                                  const bf16 *__restrict__ w1p, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  float *__restrict__ sal, int n_big) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        const int q = n_big / 8, rem = n_big % 8, x = b % 8;
+        const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+        halo_bf16_tile<NP, 4>(hsm, feat, n_rows, G, w1p, b1, w2, b2, sal, tile * 256);
+    } else {
+        halo_bf16_tile<NP, 2>(hsm, feat, n_rows, G, w1p, b1, w2, b2, sal, n_big * 256 + (b - n_big) * 128);
+    }
+}
+
 // image rows the halo kernel needs for a G x G grid (exact maximum over tile positions within one period of the pattern)
 int halo_rows(int G, long long n_rows) {
     thread_local int c_G = 0, c_val = 0;           // the scan below is ~3 000 iterations at 613 frames: remember the last answer
@@ -393,10 +405,14 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
         const int np = std::max(5, (halo_rows(G, rows) + 63) / 64);      // instantiated for 5..10 x 64 image rows
         if (np <= 10 && rows < (1LL << 31) / 2) {
             const int n_tiles = (int)((rows + 255) / 256);
+            const char *tail_env = getenv("SSLAM_CONVBF_TAIL");           // round size in tiles (one workgroup per CU); 0: all big
+            const int round = tail_env ? atoi(tail_env) : 256;
+            const int n_big = round > 0 && n_tiles > round ? n_tiles / round * round : n_tiles;
+            const int n_small = n_big < n_tiles ? (int)((rows - (long long)n_big * 256 + 127) / 128) : 0;
             const size_t lds = (size_t)2 * np * 64 * HROW;
 #define HALO(NP_)                                                                                                            \
-    hipLaunchKernelGGL((selector_bf16_halo_kernel<NP_>), dim3(n_tiles), dim3(512), lds, st, (const bf16 *)feat_bf16, (int)rows, G, \
-                       (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_tiles)
+    hipLaunchKernelGGL((selector_bf16_halo_kernel<NP_>), dim3(n_big + n_small), dim3(512), lds, st, (const bf16 *)feat_bf16, (int)rows, G, \
+                       (const bf16 *)w1_packed_bf16, b1, w2, b2, sal, n_big)
             switch (np) {
                 case 10: HALO(10); break;
                 case 9: HALO(9); break;
