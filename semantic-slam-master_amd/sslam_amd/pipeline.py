@@ -158,14 +158,17 @@ class SequencePipeline:
 
     def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None) -> torch.Tensor:
         """A0 + A1: (N, H, W, 3) uint8 -> (N, 5 + G*G, 384) fp32 tokens via the HIP ViT, `vit_chunk` frames at a time.
-        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (164 frames at 448 x 448)."""
+        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (82 frames at 448 x 448), alternating between two streams."""
         if self.vit_hip is None:
             raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
         if vit_chunk is None:
             vit_chunk = self.vit_hip.chunk_frames(self.cfg.input_size)
         out = torch.empty((images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT), dtype=torch.float32, device=self.device)
-        for a in range(0, images_u8.shape[0], vit_chunk):
-            b = min(a + vit_chunk, images_u8.shape[0])
+        # A0 runs over 16 launch groups at a time (bounds the fp32 ViT input: 3.1 GB at 448 x 448); the ViT then alternates
+        # those groups between its two streams
+        span = 16 * vit_chunk
+        for a in range(0, images_u8.shape[0], span):
+            b = min(a + span, images_u8.shape[0])
             self.vit_hip.forward_features(self.preprocess(images_u8[a:b]), out=out[a:b], chunk=vit_chunk)
         return out
 

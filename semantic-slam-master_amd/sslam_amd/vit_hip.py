@@ -4,6 +4,7 @@ workspace.  PyTorch is plumbing; no torch op takes part in the forward."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -21,6 +22,8 @@ class HipViT:
         self._keep = []
         self._rope = {}
         self._ws = None
+        self._side = None            # two side streams + their workspaces (forward_features with several launch groups)
+        self._side_ws = [None, None]
         self.w = lib.VitWeights()
         bf, f32 = self._frag, self._f32
         self.w.patch_w = bf(vit.patch_embed.weight.reshape(384, 768))
@@ -56,11 +59,11 @@ class HipViT:
 
     @staticmethod
     def chunk_frames(size: int) -> int:
-        """Frames per launch group: just under 4 x 253 row tiles of 128 tokens.  The GEMM launches run one workgroup per (row
+        """Frames per launch group: just under 2 x 253 row tiles of 128 tokens.  The GEMM launches run one workgroup per (row
         tile, column half) at two per CU and the fused MLP one per row tile, so a multiple of 253 tiles is whole rounds for all
-        of them; more rounds per launch amortise the ramp and the uneven tail of every launch (448 x 448: 41 frames = 1 round
-        14.0 k frames/s, 82 = 2 rounds 15.0 k, 164 = 4 rounds 15.2 k, 205: 15.2 k; 64 frames = a partial round: 13.3 k)."""
-        return max(1, (1012 * 128) // (5 + (size // 16) ** 2))
+        of them (448 x 448: 41 frames = 1 round 14.0 k frames/s, 82 = 2 rounds 15.0 k, 164 = 4 rounds 15.2 k on one stream;
+        64 frames = a partial round: 13.3 k).  Several groups alternate between two streams (forward_features)."""
+        return max(1, (506 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
         """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group."""
@@ -78,6 +81,31 @@ class HipViT:
         x = images.detach().float().contiguous()
         if out is None:
             out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
-        for a in range(0, n, step):
+        starts = list(range(0, n, step))
+        if len(starts) >= 2 and os.environ.get("SSLAM_VIT_STREAMS", "2") != "1":
+            # Launch groups alternate between two side streams: every launch has a ramp and an uneven tail (mean workgroup lifetime x
+            # workgroups / slots explains only 60 of the QKV launch's 86 us), and the other group's kernels fill them
+            # (tools/vit_streams.py: +3-5 % at 82 frames per group; a third stream adds nothing).  The caller's stream semantics are
+            # kept: the side streams start after the current stream's work and the current stream waits for them.
+            dev = images.device
+            cur = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            for i in (0, 1):
+                if self._side_ws[i] is None or self._side_ws[i].numel() < need:
+                    self._side_ws[i] = torch.empty(need, dtype=torch.uint8, device=dev)
+            ready = cur.record_event()
+            for i, a in enumerate(starts):
+                st = self._side[i & 1]
+                if i < 2:
+                    st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    lib.vit_forward(x[a:a + step], self.w, self._side_ws[i & 1], out=out[a:a + step])
+            for st in self._side:
+                x.record_stream(st)
+                out.record_stream(st)
+                cur.wait_stream(st)
+            return out
+        for a in starts:
             lib.vit_forward(x[a:a + step], self.w, self._ws, out=out[a:a + step])
         return out

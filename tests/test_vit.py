@@ -60,3 +60,21 @@ def test_hip_vit_matches_fp32_definition(size, frames):
     # token-wise cosine similarity: every token, not just the average
     cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
     assert float(cos.min()) > 0.995
+
+
+@pytest.mark.gpu
+def test_hip_vit_launch_groups_on_two_streams_equal_one_group():
+    """forward_features cuts the batch into launch groups and alternates them between two side streams; the result is the
+    same bits as one group (the kernels are deterministic and a frame's tokens do not depend on its group), and it is visible
+    on the caller's stream without any extra synchronisation."""
+    from sslam_amd.vit_hip import HipViT
+    _, mine = _hf_pair(1)
+    hv = HipViT(mine.cuda())
+    torch.manual_seed(3)
+    x = torch.randn(5, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        one = hv.forward_features(x, chunk=5).clone()
+        many = hv.forward_features(x, chunk=2)          # 3 groups on 2 streams
+        checksum = many.sum()                           # consumed on the current stream right away
+    assert torch.equal(one, many)
+    assert torch.isfinite(checksum)

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 RX='selector_saliency|gather_refine|sim_argmax|bn_tokens|preprocess|select_keypoints|intensity_kernel|match_finalize|refine_bf16|selector_bf16|keys_decode'
 VRX='gemm_rt_kernel|mlp_fused_kernel|attn_kernel|im2patch|prefix_rows|ln_rows'
 BENCH="$ROOT/bench.py --steps 5 --warmup 2"
-VIT="$ROOT/tools/bench_vit.py 448 164"
+VIT="$ROOT/tools/bench_vit.py 448 82"
 
 echo "[1/6] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "[2/6] kernel stats of the same command"
@@ -29,7 +29,7 @@ rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4 > /dev/null
 echo "[4/6] ViT alone: bench, kernel stats, counters of the HEAD kernels"
 python $VIT > $OUT/${TAG}_vit_bench.txt
-python $ROOT/tools/bench_vit.py 448 1 8 41 64 82 >> $OUT/${TAG}_vit_bench.txt
+python $ROOT/tools/bench_vit.py 448 1 8 41 64 164 >> $OUT/${TAG}_vit_bench.txt
 rm -rf /tmp/kv && rocprofv3 --kernel-trace --stats -d /tmp/kv -o x --output-format csv -- python $VIT > /dev/null 2>&1
 cp $(find /tmp/kv -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_vit_kernel_stats.csv
 rm -rf /tmp/pv1 /tmp/pv2 /tmp/pv3 /tmp/pv4
