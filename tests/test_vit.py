@@ -78,3 +78,25 @@ def test_hip_vit_launch_groups_on_two_streams_equal_one_group():
         checksum = many.sum()                           # consumed on the current stream right away
     assert torch.equal(one, many)
     assert torch.isfinite(checksum)
+
+
+def test_vit_weight_packs_are_permutations():
+    """Host packers (no GPU): every weight lands in the stream exactly once, rounded to bf16 (and scaled per output row where a
+    LayerScale is folded in) - a dropped or duplicated element would show as a changed multiset."""
+    import numpy as np
+
+    from sslam_amd import lib
+
+    def bf16_bits(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((1152, 384)).astype(np.float32)
+    assert np.array_equal(np.sort(lib.pack_vit_linear(w).ravel()), np.sort(bf16_bits(w).ravel()))
+    w_up = rng.standard_normal((1536, 384)).astype(np.float32)
+    w_down = rng.standard_normal((384, 1536)).astype(np.float32)
+    scale = rng.uniform(0.5, 2.0, 384).astype(np.float32)
+    got = np.sort(lib.pack_vit_mlp(w_up, w_down, scale))
+    want = np.sort(np.concatenate([bf16_bits(w_up).ravel(), bf16_bits(w_down * scale[:, None]).ravel()]))
+    assert np.array_equal(got, want)
