@@ -13,11 +13,11 @@ VRX='gemm_rt_kernel|mlp_fused_kernel|attn_kernel|im2patch|prefix_rows|ln_rows'
 BENCH="$ROOT/bench.py --steps 5 --warmup 2"
 VIT="$ROOT/tools/bench_vit.py 448 82"
 
-echo "[1/6] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-echo "[2/6] kernel stats of the same command"
+echo "[1/7] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "[2/7] kernel stats of the same command"
 rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats -d /tmp/ks -o x --output-format csv -- python $BENCH --no-cpu-baseline --no-vit > /dev/null 2>&1
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
-echo "[3/6] HBM traffic + stall counters (separate --pmc passes)"
+echo "[3/7] HBM traffic + stall counters (separate --pmc passes)"
 rm -rf /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4
 P="--kernel-trace --kernel-include-regex $RX --output-format csv -o x"
 rocprofv3 --pmc FETCH_SIZE $P -d /tmp/pm1 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
@@ -27,7 +27,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_I
 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES $P -d /tmp/pm4 \
   -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4 > /dev/null
-echo "[4/6] ViT alone: bench, kernel stats, counters of the HEAD kernels"
+echo "[4/7] ViT alone: bench, kernel stats, counters of the HEAD kernels"
 python $VIT > $OUT/${TAG}_vit_bench.txt
 python $ROOT/tools/bench_vit.py 448 1 8 41 64 164 >> $OUT/${TAG}_vit_bench.txt
 rm -rf /tmp/kv && rocprofv3 --kernel-trace --stats -d /tmp/kv -o x --output-format csv -- python $VIT > /dev/null 2>&1
@@ -39,9 +39,13 @@ rocprofv3 --pmc WRITE_SIZE $PV -d /tmp/pv2 -- python $VIT > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU $PV -d /tmp/pv3 -- python $VIT > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES GRBM_GUI_ACTIVE $PV -d /tmp/pv4 -- python $VIT > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_vit.json /tmp/pv1 /tmp/pv2 /tmp/pv3 /tmp/pv4 > /dev/null
-echo "[5/6] single-frame latency"
+echo "[5/7] single-frame latency"
 python $ROOT/tools/bench_latency.py > $OUT/${TAG}_latency.json 2>/dev/null
-echo "[6/6] library yardstick + bandwidth probe (context for the roofline fractions, not product code)"
+echo "[6/7] library yardstick + bandwidth probe (context for the roofline fractions, not product code)"
 python $ROOT/tools/yardstick_vit.py > $OUT/${TAG}_yardstick.txt
 python $ROOT/tools/bw_probe.py >> $OUT/${TAG}_yardstick.txt
+echo "[7/7] round quantisation of the conv / descriptor MLP launches, two-stream ViT groups"
+python $ROOT/tools/conv_rounds.py > $OUT/${TAG}_rounds.txt 2>/dev/null
+python $ROOT/tools/refine_rounds.py >> $OUT/${TAG}_rounds.txt 2>/dev/null
+python $ROOT/tools/vit_streams.py 82 8 >> $OUT/${TAG}_rounds.txt 2>/dev/null
 echo done
