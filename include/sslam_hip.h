@@ -8,15 +8,16 @@
  *
  * Conventions (all entries):
  *   - every pointer is a CALLER-OWNED DEVICE pointer unless the name ends in _host; the library never copies to
- *     the host and allocates nothing, with TWO documented exceptions, both stream-ordered scratch (hipMallocAsync /
- *     hipFreeAsync on `stream`, released on every return path): the batched form of sslam_sim_argmax takes
- *     n_pairs*n2*8 bytes (SSLAM_M1_VARIANT=1 selects the scratch-free form), and sslam_selector_saliency on at most
- *     six 28x28 frames (its two-workgroups-per-tile latency form) takes 16 bytes per cell (SSLAM_CONV_LAT2_ROWS=0
- *     selects the scratch-free forms);
+ *     the host and NEVER allocates or frees device memory.  The two entries whose fastest form needs scratch take it
+ *     from the caller (sslam_selector_saliency_ws, sslam_sim_argmax_ws; sizes from sslam_workspace_bytes or the
+ *     per-entry *_workspace_bytes); their forms without a workspace argument run a scratch-free launch shape with
+ *     the same bits;
  *   - `stream` is a hipStream_t passed as void* (PyTorch: torch.cuda.current_stream().cuda_stream); calls only
  *     enqueue work - no synchronisation, no host read-back;
  *   - return value: SSLAM_OK or a negative SSLAM_E_* code; launch failures are reported via hipGetLastError;
- *   - stateless and thread-safe given distinct streams / workspaces;
+ *   - stateless and thread-safe given distinct streams / workspaces.  The SSLAM_* environment variables named below
+ *     are TEST-ONLY knobs (A/B timing, forcing a launch form in the parity tests): the environment is read once,
+ *     when the library is loaded, never per call; every form they select produces the same bits;
  *   - all floating point is IEEE fp32 evaluated in the canonical order documented in oracle/sslam_oracle.h
  *     (contractions = one fused-multiply-add chain in increasing k on v_mfma_f32_32x32x2_f32), so results are
  *     bit-identical to the CPU oracle.
@@ -44,6 +45,21 @@ int sslam_version(void);
 const char *sslam_arch(void);
 /* number of kernel launches enqueued by this process so far (lets tests prove the HIP path ran) */
 long long sslam_launch_count(void);
+
+/* One caller-owned device scratch buffer (bytes, multiple of 256; 0 if none is needed) that serves every *_ws entry of
+ * a pipeline step enqueued on one stream - the stages run in stream order and share it: n_frames frames of a G x G grid
+ * through sslam_selector_saliency_ws, n_pairs pairs of K keypoints through sslam_sim_argmax_ws (n_pairs may be 0). */
+long long sslam_workspace_bytes(int n_frames, int G, int K, int n_pairs);
+/* per-entry needs (what sslam_workspace_bytes takes the maximum of) */
+long long sslam_selector_saliency_workspace_bytes(int n_frames, int G);
+long long sslam_sim_argmax_workspace_bytes(int n2, int n_pairs);
+
+/* TEST-ONLY: override one of the load-time knobs (name = its environment variable, e.g. "SSLAM_CONV_TAIL"); unset != 0
+ * restores the built-in default.  Not thread-safe against running calls; product code never calls it.  Knobs:
+ * SSLAM_M1_VARIANT, SSLAM_CONV_VARIANT, SSLAM_CONV_LATENCY_ROWS, SSLAM_CONV_LAT2_ROWS, SSLAM_CONV_NO_HALO, SSLAM_CONV_TAIL,
+ * SSLAM_CONVBF_NO_HALO, SSLAM_CONVBF_TAIL, SSLAM_CONVBF_VARIANT, SSLAM_VIT_NO_FUSED_MLP, SSLAM_VIT_FORM, SSLAM_BN_FORM,
+ * SSLAM_RT_STOP (csrc/common.h says what each selects). */
+int sslam_test_set_knob(const char *name, long long value, int unset);
 
 /* ---- weight packing (host side, plain C++; run once per checkpoint) ------------------------------------------
  * The kernels read weights in an LDS-image order: K split into chunks, each chunk stored [n][k] with k permuted
@@ -82,9 +98,15 @@ int sslam_bn_tokens(const float *tokens, int n_frames, int tokens_per_frame, int
  * (conv3x3 384->hs + ReLU + conv1x1 hs->1 + sigmoid).  feat (n_frames, G, G, 384) NHWC; w1_packed from
  * sslam_pack_conv3x3_host; b1 (hs), w2 (hs), b2 (1); hs in {128, 256}.  sal (n_frames, G, G).
  * Four launch shapes, chosen by size, all bit-identical (same fma chain per output; csrc/selector.hip): the halo
- * and the stage form of the 128-row throughput kernel, and two latency forms for few frames. */
+ * and the stage form of the 128-row throughput kernel, and two latency forms for few frames.  The second latency form
+ * (two workgroups per 32-cell tile; up to six 28x28 frames) needs 16 bytes of scratch per cell: the _ws entry takes it from
+ * the caller (workspace_bytes >= sslam_selector_saliency_workspace_bytes; workspace may be NULL: then, and in the entry
+ * without a workspace, the 8-wave latency form runs instead). */
 int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
                             const float *w2, const float *b2, int hs, float *sal, void *stream);
+int sslam_selector_saliency_ws(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
+                               const float *w2, const float *b2, int hs, float *sal, void *workspace,
+                               long long workspace_bytes, void *stream);
 
 /* ---- A3, bf16 THROUGHPUT mode (BASELINE.json configs[1] "bf16 conv stack").  Same layer as
  * sslam_selector_saliency with bf16 operands (round-to-nearest-even), fp32 accumulation on v_mfma_f32_32x32x16_bf16 and
@@ -162,12 +184,15 @@ int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, 
  * d1; nn21/s21 (n_pairs, n2): the column direction.  second12 (n_pairs, n1): the largest similarity of the row with
  * the winner removed (-inf if n2 == 1) - what the ratio tests of visualize_matches.py:116-121 and
  * test/test_descriptor_quality.py:129-131 need, without sorting rows.  s12 / s21 / second12 may be NULL.
- * Batched calls (n_pairs >= 16) evaluate the similarity matrix once and reduce the column direction with 64-bit
- * (value, ~index) keys and atomic max - deterministic - using n_pairs*n2*8 bytes of stream-ordered scratch
- * (hipMallocAsync / hipFreeAsync on `stream`); smaller calls evaluate it once per direction and allocate nothing.
- * Environment SSLAM_M1_VARIANT = 1 / 2 forces the scratch-free / the single-evaluation form. */
+ * sslam_sim_argmax_ws, batched calls (n_pairs >= 16) with workspace_bytes >= sslam_sim_argmax_workspace_bytes(n2, n_pairs)
+ * = n_pairs*n2*8 bytes of caller-owned scratch: the similarity matrix is evaluated once and the column direction reduced
+ * with 64-bit (value, ~index) keys and atomic max - deterministic.  Smaller calls, a NULL / short workspace, and the entry
+ * without a workspace evaluate it once per direction and need no scratch.  Same bits either way. */
 int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2, int n2,
                      int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12, void *stream);
+int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2, int n2,
+                        int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12,
+                        void *workspace, long long workspace_bytes, void *stream);
 
 /* ---- M1: mutual check + thresholds + quality + ordered compaction.  Replaces
  * SequenceMatcher.match_with_quality, visualize_matches_sequence.py:149-197, given the arg-max arrays above.

@@ -16,6 +16,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern long long g_sslam_launches;
 
+// TEST-ONLY knobs (A/B timing, forcing a launch form in the parity tests).  Each is read from the environment ONCE, when
+// the library is loaded (lib.hip), never per call; tests flip them through sslam_test_set_knob.  Product callers leave
+// them alone: every form a knob selects is bit-identical to the default one.
+enum sslam_knob_id {
+    KNOB_M1_VARIANT,          // SSLAM_M1_VARIANT          1: S per direction (no workspace), 2: S once + 64-bit key reduction
+    KNOB_CONV_VARIANT,        // SSLAM_CONV_VARIANT        wave tiling of the stage-form conv
+    KNOB_CONV_LATENCY_ROWS,   // SSLAM_CONV_LATENCY_ROWS   row count below which the latency forms run (0: throughput form)
+    KNOB_CONV_LAT2_ROWS,      // SSLAM_CONV_LAT2_ROWS      row count below which latency form 2 runs (0: never)
+    KNOB_CONV_NO_HALO,        // SSLAM_CONV_NO_HALO        stage form instead of the halo form
+    KNOB_CONV_TAIL,           // SSLAM_CONV_TAIL           round size in tiles of the halo form (0: all big tiles)
+    KNOB_CONVBF_NO_HALO,      // SSLAM_CONVBF_NO_HALO
+    KNOB_CONVBF_TAIL,         // SSLAM_CONVBF_TAIL
+    KNOB_CONVBF_VARIANT,      // SSLAM_CONVBF_VARIANT
+    KNOB_VIT_NO_FUSED_MLP,    // SSLAM_VIT_NO_FUSED_MLP    the two-launch MLP
+    KNOB_VIT_FORM,            // SSLAM_VIT_FORM            A/B selector of ViT launch forms (round 3)
+    KNOB_BN_FORM,             // SSLAM_BN_FORM             1: three-sweep BatchNorm kernel instead of the register-resident one
+    KNOB_RT_STOP,             // SSLAM_RT_STOP             probe builds only
+    KNOB_COUNT
+};
+#define SSLAM_KNOB_UNSET (-0x7fffffffffffffffLL - 1)
+extern long long g_sslam_knob[KNOB_COUNT];
+static inline long long sslam_knob(int id, long long dflt) { const long long v = g_sslam_knob[id]; return v == SSLAM_KNOB_UNSET ? dflt : v; }
+static inline bool sslam_knob_set(int id) { return g_sslam_knob[id] != SSLAM_KNOB_UNSET; }
+
 #define SSLAM_CHECK_LAUNCH()                                   \
     do {                                                       \
         g_sslam_launches++;                                    \

@@ -344,37 +344,37 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const int *__restri
 
 }  // namespace
 
-extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2,
-                                int n2, int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12,
-                                void *stream) {
+// scratch of the single-evaluation form: one 64-bit (value, ~index) key per (pair, candidate)
+extern "C" long long sslam_sim_argmax_workspace_bytes(int n2, int n_pairs) {
+    if (n2 <= 0 || n_pairs <= 0) return SSLAM_E_INVALID;
+    const int forced = (int)sslam_knob(KNOB_M1_VARIANT, 0);
+    if (forced == 1 || (forced == 0 && n_pairs < 16)) return 0;      // the two-pass form: no scratch
+    return (long long)n_pairs * n2 * (long long)sizeof(unsigned long long);
+}
+
+extern "C" int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2,
+                                   int n2, int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12,
+                                   void *workspace, long long workspace_bytes, void *stream) {
     if (!desc1 || !desc2 || !nn12 || !nn21 || n1 <= 0 || n2 <= 0 || n_pairs <= 0) return SSLAM_E_INVALID;
-    if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15 || (stride1 & 3) || (stride2 & 3)) return SSLAM_E_INVALID;
+    if (((uintptr_t)desc1 | (uintptr_t)desc2) & 15 || (stride1 & 3) || (stride2 & 3) || ((uintptr_t)workspace & 7)) return SSLAM_E_INVALID;
     if ((long long)n_pairs * ((((n1 > n2 ? n1 : n2) + QB - 1) / QB)) > 0x7ffffff0LL / 8) return SSLAM_E_UNSUPPORTED;
-    // variant: 0 = by batch size, 1 = S per direction (no scratch memory), 2 = S once + 64-bit key reduction
-    const char *env = getenv("SSLAM_M1_VARIANT");
-    const int forced = env ? atoi(env) : 0;
+    // test-only knob (common.h): 0 = by batch size, 1 = S per direction (no workspace), 2 = S once + 64-bit key reduction
+    const int forced = (int)sslam_knob(KNOB_M1_VARIANT, 0);
     hipStream_t st = (hipStream_t)stream;
-    if (forced == 2 || (forced == 0 && n_pairs >= 16)) {
-        unsigned long long *keys = nullptr;
-        const size_t bytes = (size_t)n_pairs * n2 * sizeof(unsigned long long);
-        if (hipMallocAsync((void **)&keys, bytes, st) != hipSuccess) return SSLAM_E_LAUNCH;   // stream-ordered scratch
-        if (hipMemsetAsync(keys, 0, bytes, st) != hipSuccess) {
-            (void)hipFreeAsync(keys, st);
-            return SSLAM_E_LAUNCH;
-        }
+    const long long need = (long long)n_pairs * n2 * (long long)sizeof(unsigned long long);
+    const bool have_ws = workspace && workspace_bytes >= need;
+    if (forced == 2 && !have_ws) return SSLAM_E_INVALID;
+    if (have_ws && (forced == 2 || (forced == 0 && n_pairs >= 16))) {
+        unsigned long long *keys = (unsigned long long *)workspace;      // CALLER-OWNED scratch: the library allocates nothing
+        if (hipMemsetAsync(keys, 0, (size_t)need, st) != hipSuccess) return SSLAM_E_LAUNCH;
         const int qb1 = (n1 + QB - 1) / QB;
         hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((unsigned)((n_pairs + 7) / 8 * 8 * qb1), 1, 1), dim3(NTM), 0, st, desc1, stride1, n1,
                            desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys, n_pairs, qb1);
-        g_sslam_launches++;
-        bool ok = hipGetLastError() == hipSuccess;
-        if (ok) {
-            const long long n = (long long)n_pairs * n2;
-            hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
-            g_sslam_launches++;
-            ok = hipGetLastError() == hipSuccess;
-        }
-        if (hipFreeAsync(keys, st) != hipSuccess) ok = false;     // the scratch is released on the failure paths too
-        return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
+        SSLAM_CHECK_LAUNCH();
+        const long long n = (long long)n_pairs * n2;
+        hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
+        SSLAM_CHECK_LAUNCH();
+        return SSLAM_OK;
     }
     const int nmax = n1 > n2 ? n1 : n2;
     const int qbm = (nmax + QB - 1) / QB;
@@ -382,6 +382,13 @@ extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, c
                        desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr, n_pairs, qbm);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
+}
+
+// the form without a workspace: never allocates - the similarity matrix is evaluated once per direction
+extern "C" int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2,
+                                int n2, int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12,
+                                void *stream) {
+    return sslam_sim_argmax_ws(desc1, stride1, n1, desc2, stride2, n2, n_pairs, nn12, s12, nn21, s21, second12, nullptr, 0, stream);
 }
 
 extern "C" int sslam_match_finalize(const int32_t *nn12, const float *s12, const int32_t *nn21, int n1, int n2, int n_pairs,

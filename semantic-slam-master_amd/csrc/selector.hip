@@ -661,30 +661,39 @@ void launch(const float *feat, long long rows, int G, const float *w1p, const fl
 
 }  // namespace
 
-extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
-                                       const float *w2, const float *b2, int hs, float *sal, void *stream) {
+// rows up to which latency form 2 runs by default: one wave per SIMD stops paying once the 50 workgroups per frame fill the
+// chip (6 frames at G = 28).  Measured (tools/conv_forms.py, G = 28): 1 / 4 / 8 / 16 frames: 0.070 / 0.077 / 0.129 / 0.247 ms
+// against 0.123 / 0.123 / 0.129 / 0.224 ms for the 8-wave latency form
+static const long long LAT2_DEFAULT_ROWS = 32 * 25 * 6;
+// few frames (the drop-in scripts call frame by frame): 128-row tiles would occupy rows / 128 of the 256 CUs for 108 serial
+// stages of 64 MFMAs; the latency form cuts a stage to 16 MFMAs per wave and uses 4x the workgroups (0.12 vs 0.47 ms for one
+// frame; still ahead at 256 frames: 2.90 vs 3.02 ms).  Measured cross-over: ~400 frames at G = 28 (6.25 vs 6.10 ms at 613)
+static const long long LAT_DEFAULT_ROWS = 128 * 1800;
+
+// scratch of latency form 2: the two half-sums of the 1x1 conv per cell and workgroup half (16 bytes per cell)
+extern "C" long long sslam_selector_saliency_workspace_bytes(int n_frames, int G) {
+    if (n_frames <= 0 || G <= 0) return SSLAM_E_INVALID;
+    const long long rows = (long long)n_frames * G * G;
+    return rows <= sslam_knob(KNOB_CONV_LAT2_ROWS, LAT2_DEFAULT_ROWS) ? rows * 16 : 0;
+}
+
+extern "C" int sslam_selector_saliency_ws(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
+                                          const float *w2, const float *b2, int hs, float *sal, void *workspace,
+                                          long long workspace_bytes, void *stream) {
     if (!feat || !w1_packed || !b1 || !w2 || !b2 || !sal || n_frames <= 0 || G <= 0) return SSLAM_E_INVALID;
-    if (((uintptr_t)feat | (uintptr_t)w1_packed) & 15) return SSLAM_E_INVALID;
+    if (((uintptr_t)feat | (uintptr_t)w1_packed | (uintptr_t)workspace) & 15) return SSLAM_E_INVALID;
     const long long rows = (long long)n_frames * G * G;
     if (rows * (long long)(SSLAM_C * 4) > 0xffffffffLL) return SSLAM_E_UNSUPPORTED;   // one buffer descriptor spans the feature map
     hipStream_t st = (hipStream_t)stream;
-    // tuning knob; measured on MI355X (613 frames, G=28): 0: 7.16 ms, 1: 7.06, 2: 6.67 (default), 3: 7.97
-    static const int variant = getenv("SSLAM_CONV_VARIANT") ? atoi(getenv("SSLAM_CONV_VARIANT")) : 2;
-    // few frames (the drop-in scripts call frame by frame): 128-row tiles would occupy rows / 128 of the 256 CUs for 108
-    // serial stages of 64 MFMAs; the latency form cuts a stage to 16 MFMAs per wave and uses 4x the workgroups (0.12 vs
-    // 0.47 ms for one frame; still ahead at 256 frames: 2.90 vs 3.02 ms)
-    const char *lat_env = getenv("SSLAM_CONV_LATENCY_ROWS");          // 0 forces the throughput form (tests, A/B timing)
-    const long long lat_rows = lat_env ? atoll(lat_env) : 128 * 1800;  // measured cross-over: ~400 frames at G = 28 (6.25 vs 6.10 ms at 613)
-    // latency form 2 up to this many rows (env SSLAM_CONV_LAT2_ROWS; 0 disables).  Measured (tools/conv_forms.py, G = 28): 1 / 4 / 8
-    // / 16 frames: 0.070 / 0.077 / 0.129 / 0.247 ms against 0.123 / 0.123 / 0.129 / 0.224 ms for the 8-wave latency form - one
-    // wave per SIMD stops paying once the 50 workgroups per frame fill the chip (6 frames)
-    const char *l2_env = getenv("SSLAM_CONV_LAT2_ROWS");
-    const long long lat2_rows = l2_env ? atoll(l2_env) : 32 * 25 * 6;
-    if (hs == 256 && rows <= lat2_rows && rows <= lat_rows) {
+    // test-only knobs (common.h), read once at load time; measured on MI355X (613 frames, G=28): variant 0: 7.16 ms, 1: 7.06, 2: 6.67 (default), 3: 7.97
+    const int variant = (int)sslam_knob(KNOB_CONV_VARIANT, 2);
+    const long long lat_rows = sslam_knob(KNOB_CONV_LATENCY_ROWS, LAT_DEFAULT_ROWS);   // 0 forces the throughput form
+    const long long lat2_rows = sslam_knob(KNOB_CONV_LAT2_ROWS, LAT2_DEFAULT_ROWS);    // 0 disables latency form 2
+    // latency form 2 needs 16 bytes of CALLER-OWNED scratch per cell; without it the 8-wave latency form runs (same bits)
+    if (hs == 256 && rows <= lat2_rows && rows <= lat_rows && workspace && workspace_bytes >= rows * 16) {
         const int np = (halo_rows32(G, rows) + 63) / 64;
         if (np <= 6) {
-            float *part = nullptr;
-            if (hipMallocAsync((void **)&part, (size_t)rows * 4 * sizeof(float), st) != hipSuccess) return SSLAM_E_LAUNCH;   // stream-ordered scratch
+            float *part = (float *)workspace;
             const int n_tiles = (int)((rows + 31) / 32);
 #define LAT2(NP_)                                                                                                              \
     hipLaunchKernelGGL((selector_saliency_lat2_kernel<NP_>), dim3(2 * n_tiles), dim3(256), 2 * NP_ * 64 * LDT * sizeof(float), st, feat, \
@@ -697,23 +706,18 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
                 default: LAT2(2); break;
             }
 #undef LAT2
-            bool ok = hipGetLastError() == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(saliency_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, b2, (int)rows, sal);
-                ok = hipGetLastError() == hipSuccess;
-            }
-            (void)hipFreeAsync(part, st);
-            g_sslam_launches += 2;
-            return ok ? SSLAM_OK : SSLAM_E_LAUNCH;
+            SSLAM_CHECK_LAUNCH();
+            hipLaunchKernelGGL(saliency_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, b2, (int)rows, sal);
+            SSLAM_CHECK_LAUNCH();
+            return SSLAM_OK;
         }
     }
     if (hs == 256 && rows <= lat_rows) {
         launch<1, 8, 1, true, 1>(feat, rows, G, w1_packed, b1, w2, b2, sal, st);
-    } else if (hs == 256 && variant == 2 && !getenv("SSLAM_CONV_NO_HALO") && halo_rows128(G, rows) <= HIMG_ROWS) {
-        // big tiles up to the last whole round of 2 workgroups x 256 CUs, 32-cell tiles for the rest (SSLAM_CONV_TAIL: the round size, 0 = all big)
+    } else if (hs == 256 && variant == 2 && !sslam_knob(KNOB_CONV_NO_HALO, 0) && halo_rows128(G, rows) <= HIMG_ROWS) {
+        // big tiles up to the last whole round of 2 workgroups x 256 CUs, 32-cell tiles for the rest
         const int n_tiles = (int)((rows + 127) / 128);
-        const char *tail_env = getenv("SSLAM_CONV_TAIL");             // round size in tiles (tests use a small one); 0: all big
-        const int round = tail_env ? atoi(tail_env) : 512;
+        const int round = (int)sslam_knob(KNOB_CONV_TAIL, 512);       // round size in tiles (tests use a small one); 0: all big
         const int n_big = round > 0 && n_tiles > round ? n_tiles / round * round : n_tiles;
         const int n_small = n_big < n_tiles ? (int)((rows - (long long)n_big * 128 + 31) / 32) : 0;
         hipLaunchKernelGGL(selector_saliency_halo_kernel, dim3(n_big + n_small), dim3(512), 2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G,
@@ -735,6 +739,12 @@ extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, c
     }
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
+}
+
+// the form without a workspace: never allocates - few-frame calls take the 8-wave latency form instead of latency form 2
+extern "C" int sslam_selector_saliency(const float *feat, int n_frames, int G, const float *w1_packed, const float *b1,
+                                       const float *w2, const float *b2, int hs, float *sal, void *stream) {
+    return sslam_selector_saliency_ws(feat, n_frames, G, w1_packed, b1, w2, b2, hs, sal, nullptr, 0, stream);
 }
 
 // w (hs, 384, 3, 3) -> [stage = chunk*9 + tap][k-group g (4)][n][8 floats in KP8 order] (MFMA B-fragment order)

@@ -401,12 +401,11 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
     const long long rows = (long long)n_frames * G * G;
     if (rows * (long long)(SSLAM_C * 2) > 0xffffffffLL) return SSLAM_E_UNSUPPORTED;   // one buffer descriptor spans the bf16 feature map
     hipStream_t st = (hipStream_t)stream;
-    if (hs == 256 && !getenv("SSLAM_CONVBF_NO_HALO")) {
+    if (hs == 256 && !sslam_knob(KNOB_CONVBF_NO_HALO, 0)) {
         const int np = std::max(5, (halo_rows(G, rows) + 63) / 64);      // instantiated for 5..10 x 64 image rows
         if (np <= 10 && rows < (1LL << 31) / 2) {
             const int n_tiles = (int)((rows + 255) / 256);
-            const char *tail_env = getenv("SSLAM_CONVBF_TAIL");           // round size in tiles (one workgroup per CU); 0: all big
-            const int round = tail_env ? atoi(tail_env) : 256;
+            const int round = (int)sslam_knob(KNOB_CONVBF_TAIL, 256);           // round size in tiles (one workgroup per CU); 0: all big
             const int n_big = round > 0 && n_tiles > round ? n_tiles / round * round : n_tiles;
             const int n_small = n_big < n_tiles ? (int)((rows - (long long)n_big * 256 + 127) / 128) : 0;
             const size_t lds = (size_t)2 * np * 64 * HROW;
@@ -427,7 +426,7 @@ extern "C" int sslam_selector_saliency_bf16(const void *feat_bf16, int n_frames,
         }
     }
     if (hs == 256) {
-        static const int variant = [] { const char *e = getenv("SSLAM_CONVBF_VARIANT"); return e ? atoi(e) : 2; }();   // measured: 0: 1.08 ms, 1: 1.28 ms, 2: 0.96 ms / 613 frames
+        const int variant = (int)sslam_knob(KNOB_CONVBF_VARIANT, 2);   // measured: 0: 1.08 ms, 1: 1.28 ms, 2: 0.96 ms / 613 frames
         if (variant == 1) {
             const int n_tiles = (int)((rows + 127) / 128);
             hipLaunchKernelGGL((selector_bf16_kernel<1, 4, 4>), dim3(n_tiles), dim3(256), 0, st, (const bf16 *)feat_bf16, (int)rows, G,

@@ -318,10 +318,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
             }
         }
         RT_STAMP(t_e0);
+#ifdef SSLAM_RT_PROBE
         if (dbg & 2) {
 #pragma unroll
             for (int s = 0; s < RT_SL; s++) asm volatile("" ::"v"(acc[s]));
         } else
+#endif
             epi.tile(acc, est, row0, nt0 + nt, stg, vec_epi + RT_NT * nt_per_part, lane, M);
         RT_STAMP(t_e1);
         RT_ACC(p_epi, t_e1, t_e0);
@@ -1094,7 +1096,9 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
     const long long rows = (long long)n_frames * T, prow = (long long)n_frames * cells;
     if (rows * VMLP > 0x7fffffffLL * 64) return SSLAM_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    { const char *e = getenv("SSLAM_RT_DBG"); g_rt_dbg = e ? atoi(e) : 0; }
+#ifdef SSLAM_RT_PROBE
+    { const char *e = getenv("SSLAM_RT_DBG"); g_rt_dbg = e ? atoi(e) : 0; }     // probe builds only (tools/rt_probe.py)
+#endif
     char *p = (char *)workspace;
     float *x = (float *)p;            p += ws_align(rows * VD * 4);
     bf16 *y = (bf16 *)p;              p += ws_align(rows * VD * 2);
@@ -1114,10 +1118,10 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
     }
     const float4 *st4 = (const float4 *)stats;
     const bool small = (rows + RT_BM - 1) / RT_BM * 4 <= 256;
-    const bool no_fused = getenv("SSLAM_VIT_NO_FUSED_MLP") != nullptr;      // A/B knob: the two-launch MLP     // <= 8 frames at 448 x 448: latency-shaped launches
+    const bool no_fused = sslam_knob(KNOB_VIT_NO_FUSED_MLP, 0) != 0;      // test-only A/B knob: the two-launch MLP     // <= 8 frames at 448 x 448: latency-shaped launches
     int rt_stop = 0;
 #ifdef SSLAM_RT_PROBE
-    { const char *e = getenv("SSLAM_RT_STOP"); rt_stop = e ? atoi(e) : 0; }
+    rt_stop = (int)sslam_knob(KNOB_RT_STOP, 0);
 #endif
     for (int L = 0; L < VLAYERS; L++) {
         const sslam_vit_layer_t &ly = w->layer[L];

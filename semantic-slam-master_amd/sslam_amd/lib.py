@@ -62,6 +62,8 @@ EXPORTS = [
     "sslam_vit_pack_linear_host", "sslam_vit_pack_mlp_host", "sslam_vit_workspace_bytes", "sslam_vit_forward",
     "sslam_f32_to_bf16", "sslam_pack_conv3x3_bf16_host", "sslam_selector_saliency_bf16",
     "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
+    "sslam_workspace_bytes", "sslam_selector_saliency_workspace_bytes", "sslam_sim_argmax_workspace_bytes",
+    "sslam_selector_saliency_ws", "sslam_sim_argmax_ws", "sslam_test_set_knob",
 ]
 
 
@@ -82,6 +84,11 @@ def lib():
         L.sslam_preprocess_u8.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, p]
         L.sslam_bn_tokens.argtypes = [p, i, i, i, i, p, p, p, p, i, f, p, p, p, p]
         L.sslam_selector_saliency.argtypes = [p, i, i, p, p, p, p, i, p, p]
+        L.sslam_selector_saliency_ws.argtypes = [p, i, i, p, p, p, p, i, p, p, ll, p]
+        for fn, at in ((L.sslam_workspace_bytes, [i, i, i, i]), (L.sslam_selector_saliency_workspace_bytes, [i, i]),
+                       (L.sslam_sim_argmax_workspace_bytes, [i, i])):
+            fn.restype, fn.argtypes = ll, at
+        L.sslam_test_set_knob.argtypes = [C.c_char_p, ll, i]
         L.sslam_select_keypoints.argtypes = [p, i, i, i, i, d, p, p, p, p, p, p]
         L.sslam_gather.argtypes = [p, i, i, p, i, p, p]
         L.sslam_refiner_layout.argtypes = [i, C.POINTER(RefinerLayout)]
@@ -90,6 +97,7 @@ def lib():
         L.sslam_gather_refine.argtypes = [p, i, i, p, i, p, i, p, p]
         L.sslam_keypoint_intensity.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, i, p, p]
         L.sslam_sim_argmax.argtypes = [p, ll, i, p, ll, i, i, p, p, p, p, p, p]
+        L.sslam_sim_argmax_ws.argtypes = [p, ll, i, p, ll, i, i, p, p, p, p, p, p, ll, p]
         L.sslam_match_finalize.argtypes = [p, p, p, i, i, i, p, ll, p, ll, p, p, f, f, f, f, f, p, p, p, p]
         L.sslam_f32_to_bf16.argtypes = [p, p, ll, p]
         L.sslam_pack_conv3x3_bf16_host.argtypes = [p, i, p]
@@ -153,6 +161,42 @@ def _dp(t):
 
 def launch_count() -> int:
     return int(lib().sslam_launch_count())
+
+
+def workspace_bytes(n_frames: int, G: int, K: int, n_pairs: int) -> int:
+    """Bytes of caller-owned scratch that serve every *_ws entry of one pipeline step on one stream (include/sslam_hip.h)."""
+    b = int(lib().sslam_workspace_bytes(n_frames, G, K, n_pairs))
+    if b < 0:
+        _check(b, "workspace_bytes")
+    return b
+
+
+def _scratch(workspace, need: int, device):
+    """The caller's workspace tensor if it is large enough, else a fresh torch allocation (the library itself never allocates)."""
+    if need <= 0:
+        return None, 0
+    if workspace is not None and workspace.numel() * workspace.element_size() >= need:
+        return workspace, workspace.numel() * workspace.element_size()
+    ws = torch.empty((need,), dtype=torch.uint8, device=device)
+    return ws, need
+
+
+class knobs:
+    """TEST-ONLY: `with lib.knobs(SSLAM_CONV_TAIL=4): ...` overrides load-time knobs of the library for the block
+    (sslam_test_set_knob) and restores the defaults afterwards.  Product code never uses it."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            _check(lib().sslam_test_set_knob(k.encode(), int(v), 0), f"set_knob({k})")
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            lib().sslam_test_set_knob(k.encode(), 0, 1)
+        return False
 
 
 # ------------------------------------------------------------------------------------------ host-side packing
@@ -237,12 +281,15 @@ def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, ep
     return out, mean, var
 
 
-def selector_saliency(feat, w1p, b1, w2, b2, hs, out=None):
+def selector_saliency(feat, w1p, b1, w2, b2, hs, out=None, workspace=None):
+    """workspace: optional caller-owned scratch tensor (sslam_workspace_bytes); allocated here through torch if absent and
+    the launch form needs one (few-frame calls only)."""
     n, g = feat.shape[0], feat.shape[1]
     if out is None:
         out = torch.empty((n, g, g), dtype=torch.float32, device=feat.device)
-    _run("selector_saliency", lib().sslam_selector_saliency, (feat, w1p, b1, w2, b2, out,),
-         _dp(feat), n, g, _dp(w1p), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out))
+    ws, wsb = _scratch(workspace, int(lib().sslam_selector_saliency_workspace_bytes(n, g)), feat.device)
+    _run("selector_saliency", lib().sslam_selector_saliency_ws, (feat, w1p, b1, w2, b2, out, ws),
+         _dp(feat), n, g, _dp(w1p), _dp(b1), _dp(w2), _dp(b2), hs, _dp(out), _dp(ws), wsb)
     return out
 
 
@@ -274,14 +321,18 @@ def selector_saliency_bf16(feat_bf16, w1p_bf16, b1, w2, b2, hs, out=None):
     return out
 
 
-def select_keypoints(sal, K, radius=2, pct=0.5, want_idx=True, want_pixel=True):
+def select_keypoints(sal, K, radius=2, pct=0.5, want_idx=True, want_pixel=True, out=None):
+    """out: optional (kp, sc, idx, px, st) tensors to write into (a launch group's slice of the caller's buffers)."""
     n, g = sal.shape[0], sal.shape[1]
     dev = sal.device
-    kp = torch.empty((n, K, 2), dtype=torch.float32, device=dev)
-    sc = torch.empty((n, K), dtype=torch.float32, device=dev)
-    idx = torch.empty((n, K), dtype=torch.int32, device=dev) if want_idx else None
-    px = torch.empty((n, K, 2), dtype=torch.float32, device=dev) if want_pixel else None
-    st = torch.empty((n,), dtype=torch.int32, device=dev)
+    if out is not None:
+        kp, sc, idx, px, st = out
+    else:
+        kp = torch.empty((n, K, 2), dtype=torch.float32, device=dev)
+        sc = torch.empty((n, K), dtype=torch.float32, device=dev)
+        idx = torch.empty((n, K), dtype=torch.int32, device=dev) if want_idx else None
+        px = torch.empty((n, K, 2), dtype=torch.float32, device=dev) if want_pixel else None
+        st = torch.empty((n,), dtype=torch.int32, device=dev)
     _run("select_keypoints", lib().sslam_select_keypoints, (sal, kp, sc, idx, px, st,),
          _dp(sal), n, g, K, radius, C.c_double(pct), _dp(kp), _dp(sc), _dp(idx), _dp(px),
                                         _dp(st))
@@ -348,24 +399,31 @@ def keypoint_intensity(img, size, tab_h, tab_v, kp_pixel, out=None):
     return out
 
 
-def sim_argmax(d1, stride1, n1, d2, stride2, n2, n_pairs, want_s21=False, want_second=False):
+def sim_argmax(d1, stride1, n1, d2, stride2, n2, n_pairs, want_s21=False, want_second=False, workspace=None):
+    """workspace: optional caller-owned scratch tensor (sslam_workspace_bytes); batched calls without one get a torch
+    allocation of n_pairs * n2 * 8 bytes here - the library itself never allocates."""
     dev = d1.device
     nn12 = torch.empty((n_pairs, n1), dtype=torch.int32, device=dev)
     s12 = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
     nn21 = torch.empty((n_pairs, n2), dtype=torch.int32, device=dev)
     s21 = torch.empty((n_pairs, n2), dtype=torch.float32, device=dev) if want_s21 else None
     sec = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev) if want_second else None
-    _run("sim_argmax", lib().sslam_sim_argmax, (nn12, s12, nn21, s21, sec, d1, d2,),
+    ws, wsb = _scratch(workspace, int(lib().sslam_sim_argmax_workspace_bytes(n2, n_pairs)), dev)
+    _run("sim_argmax", lib().sslam_sim_argmax_ws, (nn12, s12, nn21, s21, sec, d1, d2, ws),
          C.c_void_p(d1.data_ptr()), stride1, n1, C.c_void_p(d2.data_ptr()), stride2, n2, n_pairs,
-                                  _dp(nn12), _dp(s12), _dp(nn21), _dp(s21), _dp(sec))
+                                  _dp(nn12), _dp(s12), _dp(nn21), _dp(s21), _dp(sec), _dp(ws), wsb)
     return nn12, s12, nn21, s21, sec
 
 
-def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in2, w_desc, w_sal, t_sal, t_sim, t_int):
+def match_finalize(nn12, s12, nn21, n1, n2, n_pairs, sc1, ss1, sc2, ss2, in1, in2, w_desc, w_sal, t_sal, t_sim, t_int, out=None):
+    """out: optional (matches, quality, count) tensors to write into."""
     dev = nn12.device
-    matches = torch.empty((n_pairs, n1, 2), dtype=torch.int64, device=dev)
-    quality = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
-    count = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
+    if out is not None:
+        matches, quality, count = out
+    else:
+        matches = torch.empty((n_pairs, n1, 2), dtype=torch.int64, device=dev)
+        quality = torch.empty((n_pairs, n1), dtype=torch.float32, device=dev)
+        count = torch.empty((n_pairs,), dtype=torch.int32, device=dev)
     f = C.c_float
     _run("match_finalize", lib().sslam_match_finalize, (nn12, s12, nn21, matches, quality, count, sc1, sc2, in1, in2,),
          _dp(nn12), _dp(s12), _dp(nn21), n1, n2, n_pairs, C.c_void_p(sc1.data_ptr()), ss1,

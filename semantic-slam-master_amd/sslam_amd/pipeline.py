@@ -89,6 +89,23 @@ class PackedSelector:
         if bf16:
             self.w1p_bf16 = torch.from_numpy(lib.pack_conv3x3_bf16(w1)).to(device).view(torch.bfloat16)
 
+    @classmethod
+    def empty(cls, hidden: int, device, bf16: bool = False) -> "PackedSelector":
+        """Uninitialised device buffers of the packed shapes: the receiving side of the rank-0 weight broadcast (shard.py)."""
+        self = cls.__new__(cls)
+        self.hidden = int(hidden)
+        if not cls.supported((hidden, lib.C_FEAT, 3, 3)):
+            raise lib.SslamHipError(f"selector hidden {hidden} unsupported by the HIP kernels (128/256)")
+        f32 = dict(dtype=torch.float32, device=device)
+        self.w1p = torch.empty(9 * lib.C_FEAT * hidden, **f32)
+        self.b1, self.w2, self.b2 = torch.empty(hidden, **f32), torch.empty(hidden, **f32), torch.empty(1, **f32)
+        self.w1p_bf16 = torch.empty(9 * lib.C_FEAT * hidden, dtype=torch.bfloat16, device=device) if bf16 else None
+        return self
+
+    def tensors(self) -> list:
+        """Every device buffer the kernels read, in a fixed order (what broadcast_weights sends)."""
+        return [t for t in (self.w1p, self.b1, self.w2, self.b2, self.w1p_bf16) if t is not None]
+
 
 class PackedRefiner:
     """Device-resident packed DescriptorRefiner weights (one buffer, sslam_refiner_layout order)."""
@@ -104,6 +121,19 @@ class PackedRefiner:
             raise lib.SslamHipError("refiner shape unsupported by the HIP kernels (384 -> 384 -> 128)")
         self.packed = torch.from_numpy(lib.pack_refiner(ws, self.n_blocks)).to(device)
         self.packed_bf16 = torch.from_numpy(lib.pack_refiner_bf16(ws, self.n_blocks)).to(device) if bf16 else None
+
+    @classmethod
+    def empty(cls, n_blocks: int, device, bf16: bool = False) -> "PackedRefiner":
+        """Uninitialised packed buffers for `n_blocks` residual blocks (receiving side of the weight broadcast)."""
+        self = cls.__new__(cls)
+        self.n_blocks = int(n_blocks)
+        self.packed = torch.empty(int(lib.refiner_layout(n_blocks).total), dtype=torch.float32, device=device)
+        self.packed_bf16 = (torch.empty(int(lib.lib().sslam_refiner_bf16_bytes(n_blocks)), dtype=torch.uint8, device=device)
+                            if bf16 else None)
+        return self
+
+    def tensors(self) -> list:
+        return [t for t in (self.packed, self.packed_bf16) if t is not None]
 
 
 class ResampleTables:
@@ -125,17 +155,26 @@ class ResampleTables:
 
 
 class SequencePipeline:
-    def __init__(self, cfg: ExtractorConfig, selector_state: dict, refiner_state: dict, bn_state: dict | None = None,
-                 device="cuda", vit=None):
-        """vit: optional sslam_amd.vit.DinoV3ViT - enables run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ..."""
+    def __init__(self, cfg: ExtractorConfig, selector_state: dict | None, refiner_state: dict | None, bn_state: dict | None = None,
+                 device="cuda", vit=None, empty_shapes: tuple | None = None):
+        """vit: optional sslam_amd.vit.DinoV3ViT - enables run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ...
+        selector_state / refiner_state None + empty_shapes=(selector hidden, refiner blocks): uninitialised packed buffers,
+        to be filled by the rank-0 weight broadcast (shard.pipeline_from_rank0)."""
         self.cfg = cfg
         self.device = torch.device(device)
         lib.lib()   # fail loudly if the HIP library is not built
         if cfg.precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {cfg.precision!r}")
         self.bf16 = cfg.precision == "bf16"
-        self.selector = PackedSelector(selector_state, self.device, self.bf16)
-        self.refiner = PackedRefiner(refiner_state, self.device, self.bf16)
+        if selector_state is None or refiner_state is None:
+            if empty_shapes is None:
+                raise ValueError("state dicts or empty_shapes=(hidden, n_blocks) required")
+            self.selector = PackedSelector.empty(empty_shapes[0], self.device, self.bf16)
+            self.refiner = PackedRefiner.empty(empty_shapes[1], self.device, self.bf16)
+        else:
+            self.selector = PackedSelector(selector_state, self.device, self.bf16)
+            self.refiner = PackedRefiner(refiner_state, self.device, self.bf16)
+        self._ws = None             # caller-owned scratch handed to the *_ws entries (the library never allocates)
         c = lib.C_FEAT
         bn = bn_state or {}
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -148,6 +187,18 @@ class SequencePipeline:
         if vit is not None:
             from .vit_hip import HipViT
             self.vit_hip = HipViT(vit, self.device)
+
+    def weight_tensors(self) -> list:
+        """Every device buffer of packed weights / BatchNorm state, in a fixed order (6.7 MB fp32 at the shipped shapes)."""
+        return self.selector.tensors() + self.refiner.tensors() + [self.bn_gamma, self.bn_beta, self.bn_mean, self.bn_var]
+
+    def workspace(self, n_frames: int, n_pairs: int) -> torch.Tensor | None:
+        """The pipeline's scratch tensor, grown to sslam_workspace_bytes(n_frames, G, K, n_pairs): one buffer for all
+        stages of a step (they run in stream order on the caller's stream)."""
+        need = lib.workspace_bytes(max(1, n_frames), self.cfg.grid, self.cfg.num_keypoints, max(0, n_pairs))
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
 
     # ---------------------------------------------------------------------------------------------- stages
     def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
@@ -188,38 +239,55 @@ class SequencePipeline:
         saliency CNN addresses the fp32 feature map through a single descriptor: < 4 GiB per launch)."""
         return max(1, min(self.cfg.chunk_frames, (2 ** 32 - 1) // (self.cfg.grid ** 2 * lib.C_FEAT * 4)))
 
-    def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
+    def alloc_extract(self, n: int, with_intensity: bool) -> dict:
+        """Output buffers of extract() for n frames (every launch group writes its slice: nothing is concatenated)."""
+        cfg, dev = self.cfg, self.device
+        g, K = cfg.grid, cfg.num_keypoints
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = dict(saliency=torch.empty((n, g, g), **f32), keypoints_patch=torch.empty((n, K, 2), **f32),
+                   keypoints_pixel=torch.empty((n, K, 2), **f32), scores=torch.empty((n, K), **f32),
+                   idx=torch.empty((n, K), dtype=torch.int32, device=dev), descriptors=torch.empty((n, K, lib.D_OUT), **f32),
+                   status=torch.empty((n,), dtype=torch.int32, device=dev))
+        if with_intensity:
+            out["intensity"] = torch.empty((n, K), **f32)
+        return out
+
+    def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None, out: dict | None = None) -> dict:
         """A2..A9 for any number of frames (launch groups of `launch_group()` frames).  Returns device tensors; no host
-        synchronisation unless num_keypoints exceeds the number of grid cells (the only case `status` can be set)."""
+        synchronisation unless num_keypoints exceeds the number of grid cells (the only case `status` can be set).
+        out: buffers from alloc_extract (or row slices of them) to write into - the sharded runner and the streaming
+        scheduler pass slices of sequence-sized buffers, so nothing is copied afterwards."""
         n, step = tokens.shape[0], self.launch_group()
-        parts = [self._extract_group(tokens[a:a + step], None if images_u8 is None else images_u8[a:a + step])
-                 for a in range(0, n, step)]
-        out = parts[0] if len(parts) == 1 else {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        if out is None:
+            out = self.alloc_extract(n, images_u8 is not None)
+        for a in range(0, n, step):
+            b = min(a + step, n)
+            self._extract_group(tokens[a:b], None if images_u8 is None else images_u8[a:b], {k: v[a:b] for k, v in out.items()})
         if self.cfg.num_keypoints > self.cfg.grid ** 2 and bool(out["status"].any()):
             # torch.topk raises there in the reference (keypoint_selector.py:160 / :176, SURVEY H6)
             raise RuntimeError("selected index k out of range")
         return out
 
-    def _extract_group(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
+    def _extract_group(self, tokens: torch.Tensor, images_u8: torch.Tensor | None, out: dict) -> None:
         cfg, s = self.cfg, self.selector
+        ws = self.workspace(tokens.shape[0], 0)
         if self.bf16:
             feat, feat_bf = self.features(tokens, bf16_copy=True)
-            sal = lib.selector_saliency_bf16(feat_bf, s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden)
+            lib.selector_saliency_bf16(feat_bf, s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden, out=out["saliency"])
             del feat_bf
         else:
             feat = self.features(tokens)
-            sal = lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden)
-        kp, sc, idx, px, st = lib.select_keypoints(sal, cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile)
+            lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden, out=out["saliency"], workspace=ws)
+        lib.select_keypoints(out["saliency"], cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile,
+                             out=(out["keypoints_patch"], out["scores"], out["idx"], out["keypoints_pixel"], out["status"]))
         if self.bf16:
-            desc = lib.gather_refine_bf16(feat, kp, self.refiner.packed_bf16, self.refiner.n_blocks)
+            lib.gather_refine_bf16(feat, out["keypoints_patch"], self.refiner.packed_bf16, self.refiner.n_blocks, out=out["descriptors"])
         else:
-            desc = lib.gather_refine(feat, kp, self.refiner.packed, self.refiner.n_blocks)
-        out = dict(saliency=sal, keypoints_patch=kp, keypoints_pixel=px, scores=sc, idx=idx, descriptors=desc, status=st)
-        if images_u8 is not None:
+            lib.gather_refine(feat, out["keypoints_patch"], self.refiner.packed, self.refiner.n_blocks, out=out["descriptors"])
+        if images_u8 is not None and "intensity" in out:
             n, h, w, _ = images_u8.shape
             th, tv = self.tables.get(h, w, cfg.input_size, True)
-            out["intensity"] = lib.keypoint_intensity(images_u8, cfg.input_size, th, tv, px)
-        return out
+            lib.keypoint_intensity(images_u8, cfg.input_size, th, tv, out["keypoints_pixel"], out=out["intensity"])
 
     def match(self, desc, scores, intensity=None, spacing: int | None = None, halo: dict | None = None) -> dict:
         """M1 for all pairs (i, i + spacing) inside the batch.  desc (N, K, 128), scores (N, K), intensity (N, K)."""
@@ -233,17 +301,24 @@ class SequencePipeline:
                         quality=z((0, k), dtype=torch.float32, device=desc.device),
                         match_count=z((0,), dtype=torch.int32, device=desc.device))
         use_int = cfg.use_intensity and intensity is not None
-        parts = []
+        dev = desc.device
+        res = dict(matches=torch.empty((n_pairs, k, 2), dtype=torch.int64, device=dev),
+                   quality=torch.empty((n_pairs, k), dtype=torch.float32, device=dev),
+                   match_count=torch.empty((n_pairs,), dtype=torch.int32, device=dev))
+        aux = []
         for a in range(0, n_pairs, MAX_PAIRS_PER_LAUNCH):       # the pair index is a 16-bit grid dimension
             m = min(MAX_PAIRS_PER_LAUNCH, n_pairs - a)
             d1, d2 = desc[a:a + m], desc[a + sp:a + sp + m]
-            nn12, s12, nn21, _, _ = lib.sim_argmax(d1, k * lib.D_OUT, k, d2, k * lib.D_OUT, k, m)
-            mt, q, cnt = lib.match_finalize(nn12, s12, nn21, k, k, m, scores[a:], k, scores[a + sp:], k,
-                                            intensity[a:] if use_int else None, intensity[a + sp:] if use_int else None,
-                                            1.0 - cfg.saliency_weight, cfg.saliency_weight, cfg.min_saliency,
-                                            cfg.min_descriptor_sim, cfg.min_intensity)
-            parts.append(dict(matches=mt, quality=q, match_count=cnt, nn12=nn12, nn21=nn21, sim=s12))
-        return parts[0] if len(parts) == 1 else {key: torch.cat([p[key] for p in parts]) for key in parts[0]}
+            nn12, s12, nn21, _, _ = lib.sim_argmax(d1, k * lib.D_OUT, k, d2, k * lib.D_OUT, k, m, workspace=self.workspace(0, m))
+            lib.match_finalize(nn12, s12, nn21, k, k, m, scores[a:], k, scores[a + sp:], k,
+                               intensity[a:] if use_int else None, intensity[a + sp:] if use_int else None,
+                               1.0 - cfg.saliency_weight, cfg.saliency_weight, cfg.min_saliency,
+                               cfg.min_descriptor_sim, cfg.min_intensity,
+                               out=(res["matches"][a:a + m], res["quality"][a:a + m], res["match_count"][a:a + m]))
+            aux.append((nn12, nn21, s12))
+        for i, key in enumerate(("nn12", "nn21", "sim")):       # the arg-max arrays (diagnostics): one launch in practice
+            res[key] = aux[0][i] if len(aux) == 1 else torch.cat([x[i] for x in aux])
+        return res
 
     def run(self, images_u8: torch.Tensor | None, tokens: torch.Tensor | None = None, with_preprocess: bool = False) -> dict:
         """One pass of the hot path over a frame sequence: extract every frame once, match (i, i+spacing).

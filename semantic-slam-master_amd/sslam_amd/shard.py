@@ -10,13 +10,14 @@ results:
      point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link).  Those frames are extracted FIRST, as their
      own small launch group, and the isend / irecv are posted before the rest of the block is extracted - the transfer
      overlaps the bulk of the extraction;
-  2. results - rank 0 alone receives the matches, COMPACTED on the sending GPU: one int32 record (global pair index,
-     idx1, idx2, quality bits) per match, 16 bytes (the padded (pairs, K, 2) int64 + (pairs, K) fp32 arrays are 20 bytes per
+  2. results - rank 0 alone receives the matches, COMPACTED on the sending GPU: one int32 record (pair index - local on
+     the wire, turned into the sequence's pair number on rank 0 -, idx1, idx2, quality bits) per match, 16 bytes (the padded (pairs, K, 2) int64 + (pairs, K) fp32 arrays are 20 bytes per
      SLOT: 10 KB per pair at K = 500 whatever the match count).  Sizes are exchanged once per run (one 16-byte all-gather
      and the only host synchronisation of the step, after everything else has been enqueued), then every rank r > 0 does
      one send and rank 0 one recv per rank into its slice of the result.
 
-No all-reduce, no all-gather of payload, no weight traffic after the optional initial broadcast of the packed weights.
+No all-reduce, no all-gather of payload, no weight traffic after the initial broadcast of the packed weights from rank 0
+(`pipeline_from_rank0`: one rank reads and packs the checkpoint, the others receive 6.7 MB once).
 """
 from __future__ import annotations
 
@@ -33,16 +34,44 @@ def shard_bounds(n_frames: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def broadcast_weights(tensors: list, src: int = 0):
+def broadcast_weights(tensors: list, src: int = 0, group=None):
     """Rank `src` owns the checkpoint; everyone else receives the packed device buffers (6.7 MB fp32, once)."""
     for t in tensors:
-        dist.broadcast(t, src=src)
+        dist.broadcast(t, src=src, group=group)
 
 
-def compact_records(matches: torch.Tensor, quality: torch.Tensor, match_count: torch.Tensor, first_pair: int):
-    """(p, K, 2) int64 / (p, K) fp32 / (p,) counts -> ((p*K, 4) int32 buffer, device scalar M): rows 0..M-1 are (global pair
-    index, idx1, idx2, quality bits), pairs ascending and idx1 ascending inside a pair - exactly the valid slots, in order.
-    Prefix-sum + scatter on the device: no host synchronisation (boolean-mask indexing would need one)."""
+def pipeline_from_rank0(cfg, selector_state: dict | None, refiner_state: dict | None, device, bn_state: dict | None = None,
+                        src: int = 0, group=None):
+    """rank `src` alone reads the checkpoint and packs the weights into kernel order; the other ranks
+    (selector_state = refiner_state = None) allocate the packed buffers uninitialised and receive them by broadcast
+    (RCCL over xGMI on the GPUs; gloo in the CPU tests).  A three-number header (selector hidden width, residual blocks,
+    BatchNorm-state flag) travels first so that the receivers can size their buffers.  Returns this rank's SequencePipeline."""
+    from .pipeline import SequencePipeline, refiner_weight_list
+    rank = dist.get_rank(group)
+    dev = torch.device(device)
+    head = torch.zeros(3, dtype=torch.int64, device=dev)
+    if rank == src:
+        if selector_state is None or refiner_state is None:
+            raise ValueError(f"rank {src} must hold the state dicts")
+        head[0] = int(tuple(selector_state["conv.0.weight"].shape)[0])
+        head[1] = refiner_weight_list(refiner_state)[1]
+        head[2] = 1
+    dist.broadcast(head, src=src, group=group)
+    hidden, n_blocks, ok = (int(v) for v in head.tolist())
+    if not ok:
+        raise RuntimeError("weight broadcast header missing")
+    if rank == src:
+        pipe = SequencePipeline(cfg, selector_state, refiner_state, bn_state, device=dev)
+    else:
+        pipe = SequencePipeline(cfg, None, None, None, device=dev, empty_shapes=(hidden, n_blocks))
+    broadcast_weights(pipe.weight_tensors(), src=src, group=group)
+    return pipe
+
+
+def compact_records(matches: torch.Tensor, quality: torch.Tensor, match_count: torch.Tensor, first_pair: int = 0):
+    """(p, K, 2) int64 / (p, K) fp32 / (p,) counts -> ((p*K, 4) int32 buffer, device scalar M): rows 0..M-1 are (pair index
+    + first_pair, idx1, idx2, quality bits), pairs ascending and idx1 ascending inside a pair - exactly the valid slots, in
+    order.  Prefix-sum + scatter on the device: no host synchronisation (boolean-mask indexing would need one)."""
     p, K = quality.shape
     dev = quality.device
     buf = torch.zeros((p * K + 1, 4), dtype=torch.int32, device=dev)          # last row: dump slot for the padding
@@ -60,12 +89,20 @@ def compact_records(matches: torch.Tensor, quality: torch.Tensor, match_count: t
 
 
 def expand_records(rec: torch.Tensor, n_pairs: int, K: int) -> dict:
-    """Inverse of compact_records on the receiving side: the padded arrays of a single-process run."""
+    """Inverse of compact_records on the receiving side: the padded arrays of a single-process run.
+    The records must be what compact_records emits - pair indices in [0, n_pairs), non-decreasing, at most K per pair;
+    anything else raises ValueError here instead of an out-of-bounds indexed write on the device."""
     dev = rec.device
     matches = torch.zeros((n_pairs, K, 2), dtype=torch.int64, device=dev)
     quality = torch.zeros((n_pairs, K), dtype=torch.float32, device=dev)
     pair = rec[:, 0].long()
+    if rec.shape[0]:
+        bad = (pair < 0).any() | (pair >= n_pairs).any() | (pair[1:] < pair[:-1]).any()
+        if bool(bad):
+            raise ValueError("match records out of order or out of range (pair index must be non-decreasing in [0, n_pairs))")
     count = torch.bincount(pair, minlength=n_pairs).to(torch.int32)
+    if rec.shape[0] and int(count.max()) > K:
+        raise ValueError(f"more than K = {K} match records for one pair")
     start = torch.cumsum(count, 0) - count
     slot = torch.arange(rec.shape[0], device=dev) - start[pair]
     matches[pair, slot, 0] = rec[:, 1].long()
@@ -74,12 +111,22 @@ def expand_records(rec: torch.Tensor, n_pairs: int, K: int) -> dict:
     return dict(all_matches=matches, all_quality=quality, all_match_count=count)
 
 
+def _takes_out(fn) -> bool:
+    import inspect
+    try:
+        return "out" in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class ShardedSequenceRunner:
-    """extract_fn(tokens, images) -> dict with 'descriptors' (n, K, D), 'scores' (n, K), optional 'intensity' (n, K)
+    """extract_fn(tokens, images[, out]) -> dict with 'descriptors' (n, K, D), 'scores' (n, K), optional 'intensity' (n, K);
+    if it takes `out` (a dict of row slices of preallocated buffers, as SequencePipeline.extract does) the block's outputs
+    are written straight into block-sized buffers - no concatenation of the boundary group and the rest.
     match_fn(desc, scores, intensity, spacing) -> dict with 'matches' (p, K, 2) int64, 'quality' (p, K), 'match_count' (p,)
     Both run on this rank's device; in production they are SequencePipeline.extract / .match.
-    `first_frame` = global index of this rank's first frame (shard_bounds(...)[0]); it turns local pair numbers into the
-    sequence's pair numbers in the gathered records."""
+    Pair numbers in the gathered records are the SEQUENCE's pair numbers: every rank sends local pair indices and rank 0
+    adds the exclusive prefix sum of the ranks' pair counts (from the size exchange) - callers pass no offset."""
 
     def __init__(self, extract_fn: Callable, match_fn: Callable, spacing: int = 1, group=None):
         self.extract_fn, self.match_fn, self.spacing, self.group = extract_fn, match_fn, spacing, group
@@ -87,56 +134,67 @@ class ShardedSequenceRunner:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     # ------------------------------------------------------------------------------------------------ halo
-    def _post_halo(self, head: dict):
-        """Post the sends of my first `spacing` frames to rank-1 and the receives from rank+1; returns (requests, recv)."""
-        sp, r, w = self.spacing, self.rank, self.world
-        ops, recv = [], {}
-        for name, t in head.items():
+    def _post_halo(self, send: dict, recv: dict):
+        """Post the sends of my first `spacing` frames (`send`: name -> (sp, ...) tensor) to rank-1 and the receives from
+        rank+1 into `recv` (name -> (sp, ...) view of the block buffer's halo rows); returns the requests."""
+        r, w = self.rank, self.world
+        ops = []
+        for name, t in send.items():
             if t is None:
                 continue
             if r > 0:
-                ops.append(dist.P2POp(dist.isend, t[:sp].contiguous(), r - 1, self.group))
+                ops.append(dist.P2POp(dist.isend, t, r - 1, self.group))
             if r < w - 1:
-                recv[name] = torch.empty((sp,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
                 ops.append(dist.P2POp(dist.irecv, recv[name], r + 1, self.group))
-        return (dist.batch_isend_irecv(ops) if ops else []), recv
+        return dist.batch_isend_irecv(ops) if ops else []
 
     # ------------------------------------------------------------------------------------------------- run
-    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True, first_frame: int = 0) -> dict:
+    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True) -> dict:
         """Processes this rank's block.  Every rank must hold at least `spacing` frames."""
         sp, n = self.spacing, tokens_local.shape[0]
         assert n >= sp, "each shard needs at least `spacing` frames"
         names = ("descriptors", "scores", "intensity")
-        reqs, halo = [], {}
-        if self.world > 1 and n > sp:
-            # boundary frames first: their descriptors travel while the rest of the block is being extracted
-            ex_head = self.extract_fn(tokens_local[:sp], None if images_local is None else images_local[:sp])
-            reqs, halo = self._post_halo({k: ex_head.get(k) for k in names})
-            ex_tail = self.extract_fn(tokens_local[sp:], None if images_local is None else images_local[sp:])
-            ex = {k: torch.cat([ex_head[k], ex_tail[k]]) for k in ex_head}
-        else:
+        img = (lambda a, b: None if images_local is None else images_local[a:b])
+        if self.world == 1:
             ex = self.extract_fn(tokens_local, images_local)
-            if self.world > 1:
-                reqs, halo = self._post_halo({k: ex.get(k) for k in names})
-        for req in reqs:
-            req.wait()
-        fields = {k: ex.get(k) for k in names}
-        if halo:
-            fields = {k: (None if v is None else torch.cat([v, halo[k]])) for k, v in fields.items()}
+            fields = {k: ex.get(k) for k in names}
+        else:
+            # boundary frames first, as their own small launch group: their descriptors travel while the rest of the block
+            # is being extracted.  Block buffers hold n rows + `sp` halo rows for the fields the matcher reads, so the
+            # boundary group, the rest of the block and the neighbour's halo all land in place.
+            n_halo = sp if self.rank < self.world - 1 else 0
+            ex_head = self.extract_fn(tokens_local[:sp], img(0, sp))
+            full = {k: torch.empty((n + (n_halo if k in names else 0),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                    for k, v in ex_head.items() if isinstance(v, torch.Tensor)}
+            for k, v in full.items():
+                v[:sp] = ex_head[k]
+            reqs = self._post_halo({k: (full[k][:sp] if k in full else None) for k in names},
+                                   {k: full[k][n:n + sp] for k in names if k in full})
+            if n > sp:
+                if _takes_out(self.extract_fn):
+                    self.extract_fn(tokens_local[sp:], img(sp, n), out={k: v[sp:n] for k, v in full.items()})
+                else:
+                    ex_tail = self.extract_fn(tokens_local[sp:], img(sp, n))
+                    for k, v in full.items():
+                        v[sp:n] = ex_tail[k]
+            for req in reqs:
+                req.wait()
+            ex = {k: v[:n] for k, v in full.items()}
+            fields = {k: full.get(k) for k in names}      # n + halo rows
         m = self.match_fn(fields["descriptors"], fields["scores"], fields["intensity"], sp)   # every local i that has a partner
         out = dict(ex)
         out.update(m)
         out["n_local_pairs"] = int(m["match_count"].shape[0])
         if gather_results and self.world > 1:
-            out.update(self._gather(m, first_frame))
+            out.update(self._gather(m))
         return out
 
     # ---------------------------------------------------------------------------------------------- gather
-    def _gather(self, m: dict, first_frame: int) -> dict:
+    def _gather(self, m: dict) -> dict:
         """Compacted match records -> rank 0 (module docstring, item 2).  Rank 0 returns the padded arrays of the whole
         sequence ('all_matches', 'all_quality', 'all_match_count') and the raw records; other ranks only the sizes."""
         w, r = self.world, self.rank
-        rec, n_valid = compact_records(m["matches"], m["quality"], m["match_count"], first_frame)
+        rec, n_valid = compact_records(m["matches"], m["quality"], m["match_count"])      # LOCAL pair indices
         dev = rec.device
         sizes = torch.stack([torch.tensor(m["match_count"].shape[0], dtype=torch.int64, device=dev), n_valid])
         all_sizes = [torch.zeros_like(sizes) for _ in range(w)]
@@ -156,6 +214,12 @@ class ShardedSequenceRunner:
                 off += nrec[src]
             for req in (dist.batch_isend_irecv(ops) if ops else []):
                 req.wait()
+            # local -> sequence pair numbers: rank src's pairs start at the sum of the pair counts of the ranks before it
+            off, first = nrec[0], pairs[0]
+            for src in range(1, w):
+                if nrec[src]:
+                    buf[off:off + nrec[src], 0] += first
+                off, first = off + nrec[src], first + pairs[src]
             res["records"] = buf
             res.update(expand_records(buf, sum(pairs), K))
         elif nrec[r]:

@@ -21,7 +21,7 @@ class HipViT:
         self.vit, self.device = vit, torch.device(device)
         self._keep = []
         self._rope = {}
-        self._ws = None
+        self.n_streams = 2          # launch groups alternate between two streams (1: single stream; tools/vit_streams.py A/B)
         self._side = None            # two side streams + their workspaces (forward_features with several launch groups)
         self._side_ws = [None, None]
         self.w = lib.VitWeights()
@@ -76,13 +76,11 @@ class HipViT:
         self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
         step = chunk or self.chunk_frames(s)
         need = lib.vit_workspace_bytes(min(n, step), s)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         x = images.detach().float().contiguous()
         if out is None:
             out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
         starts = list(range(0, n, step))
-        if len(starts) >= 2 and os.environ.get("SSLAM_VIT_STREAMS", "2") != "1":
+        if len(starts) >= 2 and self.n_streams >= 2:
             # Launch groups alternate between two side streams: every launch has a ramp and an uneven tail (mean workgroup lifetime x
             # workgroups / slots explains only 60 of the QKV launch's 86 us), and the other group's kernels fill them
             # (tools/vit_streams.py: +3-5 % at 82 frames per group; a third stream adds nothing).  The caller's stream semantics are
@@ -91,7 +89,7 @@ class HipViT:
             cur = torch.cuda.current_stream(dev)
             if self._side is None:
                 self._side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-            for i in (0, 1):
+            for i in (0, 1):          # one workspace per stream; [0] doubles as the single-stream workspace (never both at once)
                 if self._side_ws[i] is None or self._side_ws[i].numel() < need:
                     self._side_ws[i] = torch.empty(need, dtype=torch.uint8, device=dev)
             ready = cur.record_event()
@@ -106,6 +104,8 @@ class HipViT:
                 out.record_stream(st)
                 cur.wait_stream(st)
             return out
+        if self._side_ws[0] is None or self._side_ws[0].numel() < need:
+            self._side_ws[0] = torch.empty(need, dtype=torch.uint8, device=self.device)
         for a in starts:
-            lib.vit_forward(x[a:a + step], self.w, self._ws, out=out[a:a + step])
+            lib.vit_forward(x[a:a + step], self.w, self._side_ws[0], out=out[a:a + step])
         return out

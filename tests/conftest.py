@@ -10,3 +10,22 @@ for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROO
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest
+
+
+@pytest.fixture
+def knob():
+    """Set a TEST-ONLY load-time knob of libsslam_hip.so for one test (sslam_test_set_knob; the library reads the
+    environment once at load, never per call) and restore the built-in default afterwards."""
+    from sslam_amd import lib
+    touched = []
+
+    def _set(name, value):
+        lib._check(lib.lib().sslam_test_set_knob(name.encode(), int(value), 0), f"set_knob({name})")
+        touched.append(name)
+
+    yield _set
+    for name in touched:
+        lib.lib().sslam_test_set_knob(name.encode(), 0, 1)

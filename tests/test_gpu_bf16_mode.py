@@ -76,9 +76,9 @@ def test_bn_tokens_bf16_copy(T, hip):
 
 @pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256), (60, 2, 256), (40, 3, 256)])
 @pytest.mark.parametrize("tail", [None, "2"])
-def test_selector_saliency_bf16(T, hip, grid, frames, hidden, tail, monkeypatch):
+def test_selector_saliency_bf16(T, hip, grid, frames, hidden, tail, knob):
     if tail:            # rounds of 2 big tiles: the remaining rows run as 128-cell tiles in the same launch
-        monkeypatch.setenv("SSLAM_CONVBF_TAIL", tail)
+        knob("SSLAM_CONVBF_TAIL", tail)
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
     feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
     w1p = dev(T, hip.pack_conv3x3_bf16(sd["conv.0.weight"])).view(T.bfloat16)

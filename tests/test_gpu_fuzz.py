@@ -67,8 +67,8 @@ def test_fuzz_select_keypoints(T, hip, seed):
 
 @pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("seed", range(4))
-def test_fuzz_sim_argmax_and_match(T, hip, seed, variant, monkeypatch):
-    monkeypatch.setenv("SSLAM_M1_VARIANT", variant)
+def test_fuzz_sim_argmax_and_match(T, hip, seed, variant, knob):
+    knob("SSLAM_M1_VARIANT", variant)
     rng = np.random.Generator(np.random.PCG64(777 + seed))
     for case in range(6):
         n, m = int(rng.integers(1, 700)), int(rng.integers(1, 700))

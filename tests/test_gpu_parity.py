@@ -93,16 +93,16 @@ def _packed_selector(T, hip, sd):
 
 @pytest.mark.parametrize("form", ["latency2", "latency", "throughput", "throughput_tail", "throughput_stage"])
 @pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (60, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256)])
-def test_selector_saliency(T, hip, grid, frames, hidden, form, monkeypatch):
+def test_selector_saliency(T, hip, grid, frames, hidden, form, knob):
     """Every launch shape of the conv, all bit-identical: 32-cell tiles split over two workgroups on the halo image (few
     frames), 32-row workgroups of 8 waves, 128-row workgroups on the halo image (G = 28), the same with the last partial round cut into 32-cell tiles, and the
     stage-per-tap form."""
-    monkeypatch.setenv("SSLAM_CONV_LATENCY_ROWS", "0" if form.startswith("throughput") else str(1 << 30))
-    monkeypatch.setenv("SSLAM_CONV_LAT2_ROWS", str(1 << 30) if form == "latency2" else "0")
+    knob("SSLAM_CONV_LATENCY_ROWS", "0" if form.startswith("throughput") else str(1 << 30))
+    knob("SSLAM_CONV_LAT2_ROWS", str(1 << 30) if form == "latency2" else "0")
     if form == "throughput_stage":
-        monkeypatch.setenv("SSLAM_CONV_NO_HALO", "1")
+        knob("SSLAM_CONV_NO_HALO", "1")
     if form == "throughput_tail":
-        monkeypatch.setenv("SSLAM_CONV_TAIL", "4")          # rounds of 4 big tiles: the rest of the rows go to 32-cell tiles
+        knob("SSLAM_CONV_TAIL", "4")          # rounds of 4 big tiles: the rest of the rows go to 32-cell tiles
     sd = synth.selector_state(0 if hidden == 256 else 1, hidden=hidden)
     feat = ora.bn_tokens(synth.tokens(20 + grid, grid, frames))[0].reshape(frames, grid, grid, 384)
     w1p, b1, w2, b2, hs = _packed_selector(T, hip, sd)
@@ -291,10 +291,10 @@ def test_batched_pairs_and_strides(T, hip):
 
 @pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("n,m,dup", [(500, 500, 40), (33, 70, 5), (700, 129, 60), (128, 1, 0), (1, 300, 0), (1024, 1000, 100)])
-def test_sim_argmax_both_forms(T, hip, variant, n, m, dup, monkeypatch):
+def test_sim_argmax_both_forms(T, hip, variant, n, m, dup, knob):
     """SSLAM_M1_VARIANT=1: S per direction; =2: S once + 64-bit key reduction for the column direction (the form batched
     calls use).  Both must give the oracle's first-maximum indices (duplicated descriptors = exact ties) and values."""
-    monkeypatch.setenv("SSLAM_M1_VARIANT", variant)
+    knob("SSLAM_M1_VARIANT", variant)
     d1, d2, *_ = _pair(900 + n + m, n, m, dup)
     pairs = 3
     D1 = dev(T, np.stack([d1, d1[::-1], d1]))

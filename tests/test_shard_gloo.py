@@ -60,24 +60,41 @@ def _pack(desc, sc, inten):
     return torch.from_numpy(np.concatenate([desc, sc[..., None], inten[..., None]], axis=-1))
 
 
-def _worker(rank, world, port, n_frames, spacing, q):
+def _worker(rank, world, port, n_frames, spacing, q, in_place=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from sslam_amd.shard import ShardedSequenceRunner, broadcast_weights, shard_bounds
+        from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+        from sslam_amd.shard import ShardedSequenceRunner, pipeline_from_rank0, shard_bounds
         desc, sc, inten = _make_inputs(n_frames)
         lo, hi = shard_bounds(n_frames, world, rank)
-        w = torch.full((7,), float(rank))
-        broadcast_weights([w], src=0)
-        assert float(w.sum()) == 0.0
+        # only rank 0 holds the state dicts; the others receive the PACKED selector / refiner buffers
+        ssd, rsd = synth.selector_state(0, hidden=128), synth.refiner_state(0, n_blocks=1)
+        pipe = pipeline_from_rank0(ExtractorConfig(), ssd if rank == 0 else None, rsd if rank == 0 else None, "cpu")
+        want = SequencePipeline(ExtractorConfig(), ssd, rsd, device="cpu")
+        assert pipe.selector.hidden == 128 and pipe.refiner.n_blocks == 1
+        got_w, want_w = pipe.weight_tensors(), want.weight_tensors()
+        assert len(got_w) == len(want_w) == 9
+        for a, b in zip(got_w, want_w):
+            assert a.shape == b.shape and torch.equal(a.view(torch.uint8), b.view(torch.uint8))
         calls = []
 
-        def extract(tokens, images):
+        def extract(tokens, images, out=None):
             calls.append(tokens.shape[0])
-            return _extract(tokens, images)
+            ex = _extract(tokens, images)
+            if out is None:
+                return ex
+            assert in_place, "out= passed to an extract function that does not take it"
+            for k, v in ex.items():
+                out[k][:] = v
+            return out
 
-        runner = ShardedSequenceRunner(extract, _match, spacing=spacing)
-        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), first_frame=lo)
+        def extract_plain(tokens, images):
+            return extract(tokens, images)
+
+        runner = ShardedSequenceRunner(extract if in_place else extract_plain, _match, spacing=spacing)
+        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]))      # no frame offset from the caller
+        assert out["descriptors"].shape[0] == hi - lo and torch.equal(out["descriptors"], _extract(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), None)["descriptors"])
         # the boundary frames go first, as their own group, whenever the block is longer than the halo
         assert calls == ([spacing, hi - lo - spacing] if hi - lo > spacing else [hi - lo]), calls
         if rank == 0:
@@ -89,8 +106,8 @@ def _worker(rank, world, port, n_frames, spacing, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,spacing", [(2, 9, 1), (3, 11, 2), (2, 4, 2), (4, 14, 1)])
-def test_sharded_equals_single_process(world, n_frames, spacing):
+@pytest.mark.parametrize("world,n_frames,spacing,in_place", [(2, 9, 1, True), (3, 11, 2, True), (2, 4, 2, True), (4, 14, 1, True), (3, 10, 1, False)])
+def test_sharded_equals_single_process(world, n_frames, spacing, in_place):
     from sslam_amd.shard import shard_bounds
     # partition covers every frame exactly once, contiguously
     edges = [shard_bounds(n_frames, world, r) for r in range(world)]
@@ -98,7 +115,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place)) for r in range(world)]
     for p in procs:
         p.start()
     cnt, mt, qual, per_rank, records, rec_per_rank = q.get(timeout=120)
@@ -118,3 +135,57 @@ def test_sharded_equals_single_process(world, n_frames, spacing):
     want = np.concatenate([ref["matches"].numpy()[i, :c] for i, c in enumerate(cnt)])
     assert np.array_equal(records[:, 1:3], want)
     assert records.nbytes == 16 * int(cnt.sum()) < mt.nbytes + qual.nbytes      # padded arrays: 20 bytes per SLOT
+
+
+def test_expand_records_rejects_malformed_records():
+    """Records that compact_records cannot have produced (pair numbers out of order / out of range, more than K per pair)
+    raise a Python error instead of an out-of-bounds indexed write (ADVICE r2, shard.py)."""
+    from sslam_amd.shard import compact_records, expand_records
+    K = 4
+    mt = torch.zeros((3, K, 2), dtype=torch.int64)
+    q = torch.rand((3, K))
+    cnt = torch.tensor([2, 0, 3], dtype=torch.int32)
+    for i in range(3):
+        mt[i, :, 0] = torch.arange(K) + 10 * i
+        mt[i, :, 1] = torch.arange(K) + 100 * i
+    rec, nv = compact_records(mt, q, cnt)
+    rec = rec[: int(nv)]
+    back = expand_records(rec, 3, K)
+    assert torch.equal(back["all_match_count"], cnt)
+    for i in range(3):
+        c = int(cnt[i])
+        assert torch.equal(back["all_matches"][i, :c], mt[i, :c]) and torch.equal(back["all_quality"][i, :c], q[i, :c])
+    shuffled = rec.flip(0)
+    with pytest.raises(ValueError):
+        expand_records(shuffled, 3, K)
+    with pytest.raises(ValueError):
+        expand_records(rec, 2, K)                          # pair index 2 out of range
+    dup = torch.cat([rec[:2], rec[:2], rec[:2]])           # 6 records for pair 0 > K... sorted, in range
+    with pytest.raises(ValueError):
+        expand_records(dup, 3, K)
+
+
+def test_bench_launch_plan():
+    """bench.py --gpus N decides, before touching a GPU, between running as one rank, starting the N ranks itself, and
+    failing: it never reports a smaller job as N GPUs (VERDICT r2 #1)."""
+    import bench
+    assert bench.launch_plan(1, {}, 1)[0] == "run"
+    assert bench.launch_plan(1, {}, 0)[0] == "run"                      # the GPU assertion comes later, with its own message
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8"}, 8)[0] == "run"     # under torch.distributed.run
+    assert bench.launch_plan(2, {}, 8)[0] == "spawn"
+    assert bench.launch_plan(8, {}, 8)[0] == "spawn"
+    act, msg = bench.launch_plan(2, {}, 1)                              # a 1-GPU box asked for 2
+    assert act == "error" and "only 1 GPU" in msg
+    assert bench.launch_plan(4, {"WORLD_SIZE": "2"}, 8)[0] == "error"
+    assert bench.launch_plan(2, {"WORLD_SIZE": "1"}, 8)[0] == "error"   # the old escape hatch (world == 1) is gone
+    assert bench.launch_plan(0, {}, 8)[0] == "error"
+
+
+def test_bench_exits_nonzero_when_gpus_are_missing():
+    """`python bench.py --gpus 2` where fewer than 2 GPUs are visible (here: none) exits non-zero with a message and
+    prints no JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and "{" not in r.stdout

@@ -80,7 +80,7 @@ if __name__ == "__main__":
     toks = torch.from_numpy(synth.token_sequence(8, 28)).to(dev)
     imgs = torch.from_numpy(synth.image_sequence(8)).to(dev)
     res = measure(vp, toks, imgs, vit_pipe=vp)
-    os.environ["SSLAM_CONV_LATENCY_ROWS"] = "0"
-    res["A3_throughput_form_ms"] = round(_timed(lambda: vp.extract(toks[:1], imgs[:1]), 50), 4)
-    os.environ.pop("SSLAM_CONV_LATENCY_ROWS")
+    from sslam_amd import lib
+    with lib.knobs(SSLAM_CONV_LATENCY_ROWS=0):
+        res["A3_throughput_form_ms"] = round(_timed(lambda: vp.extract(toks[:1], imgs[:1]), 50), 4)
     print(json.dumps(res, indent=1))

@@ -10,7 +10,7 @@ import synth
 from sslam_amd import lib
 from sslam_amd.pipeline import PackedSelector
 
-os.environ["SSLAM_CONV_LATENCY_ROWS"] = "0"
+lib.lib().sslam_test_set_knob(b"SSLAM_CONV_LATENCY_ROWS", 0, 0)
 sel = PackedSelector(synth.selector_state(0), "cuda")
 for tiles in (512, 1024, 3072, 3584, 3584 + 86, 3584 + 170, 3584 + 256, 3584 + 342, 4096):
     n = tiles // 2
@@ -18,7 +18,7 @@ for tiles in (512, 1024, 3072, 3584, 3584 + 86, 3584 + 170, 3584 + 256, 3584 + 3
     out = torch.empty(n, 16, 16, device="cuda")
     row = []
     for tail in ("0", "512"):
-        os.environ["SSLAM_CONV_TAIL"] = tail
+        lib.lib().sslam_test_set_knob(b"SSLAM_CONV_TAIL", int(tail), 0)
         for _ in range(3):
             lib.selector_saliency(feat, sel.w1p, sel.b1, sel.w2, sel.b2, sel.hidden, out=out)
         torch.cuda.synchronize()

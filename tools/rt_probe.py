@@ -24,7 +24,7 @@ hv = HipViT(DinoV3ViT().cuda().eval())
 img = torch.randn(n, 3, 448, 448, device=dev)
 names = ["lifetime", "prologue", "wait+barrier", "mfma loop", "epilogue", "gelu+exchange (fused MLP)"]
 for stop, label in [(1, "QKV (ProLN, EpiQKV)"), (2, "o_proj (ProBf16, EpiResidual)"), (3, "MLP: fused kernel, or up (ProLN, EpiGelu) with SSLAM_VIT_NO_FUSED_MLP=1"), (4, "down (ProBf16 x4, EpiResidual) with SSLAM_VIT_NO_FUSED_MLP=1")]:
-    os.environ["SSLAM_RT_STOP"] = str(stop)
+    L.sslam_test_set_knob(b"SSLAM_RT_STOP", stop, 0)
     for _ in range(2):
         hv.forward_features(img, chunk=n)
     torch.cuda.synchronize()
