@@ -186,6 +186,11 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
+    ap.add_argument("--no-upload", action="store_true", help="skip the host-resident-frames leg (overlapped H2D feed)")
+    ap.add_argument("--tum-root", default=None, help="a TUM RGB-D sequence directory (rgb/*.png ...) for the directory -> matches leg; "
+                    "absent or not given: a synthetic directory of the workload's first frames is written to a temp dir")
+    ap.add_argument("--tum-frames", type=int, default=128, help="frames of the directory leg (synthetic directory size / max_frames)")
+    ap.add_argument("--no-directory", action="store_true", help="skip the directory -> matches leg")
     args = ap.parse_args()
 
     # nothing above this line and nothing in launch_plan touches a GPU (torch.cuda.device_count() only counts devices)
@@ -335,6 +340,85 @@ def main():
         latency = bench_latency.measure(pipe_v, toks[:8], imgs[:8], vit_pipe=pipe_v, reps=50)
         del pipe_v
 
+    # additional leg (N = 1): the frames start in HOST memory (pinned uint8, as a decoder would leave them) and are uploaded in
+    # chunks on a side stream while the previous chunk is extracted and matched (sslam_amd.harness.run_frames); tokens-in
+    # mode like `value`.  Beside it: the raw H2D rate of the same bytes, i.e. the PCIe bound on frames/s.
+    upload_leg = None
+    if world == 1 and not args.no_upload:
+        from sslam_amd.harness import run_frames
+        imgs_pin = imgs.cpu().pin_memory()
+        probe = torch.empty_like(imgs)
+        for _ in range(2):
+            probe.copy_(imgs_pin, non_blocking=True)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(3):
+            probe.copy_(imgs_pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_s = (time.perf_counter() - tp) / 3
+        del probe
+        for _ in range(max(1, args.warmup)):
+            ou = run_frames(pipe, n, h, w, spacings=(cfg.spacing,), tokens=toks, pinned_source=imgs_pin, first_chunk=16)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for _ in range(args.steps):
+            ou = run_frames(pipe, n, h, w, spacings=(cfg.spacing,), tokens=toks, pinned_source=imgs_pin, first_chunk=16)
+        torch.cuda.synchronize()
+        dtu = (time.perf_counter() - tu) / args.steps
+        same = bool(torch.equal(ou[cfg.spacing]["matches"], out["matches"]) and torch.equal(ou[cfg.spacing]["match_count"], out["match_count"])
+                    and torch.equal(ou["frames"]["descriptors"], out["descriptors"]))
+        pcie_fps, resident_fps = n / h2d_s, n * args.steps / dt
+        upload_leg = {"value": round(n / dtu, 2), "unit": "frames/s", "ms_per_step": round(dtu * 1e3, 3),
+                      "what": "pinned host uint8 frames -> chunked H2D on a side stream overlapping extract + match of the previous chunk "
+                              "(tokens resident, as in `value`)",
+                      "h2d_gb_s": round(imgs_pin.numel() / h2d_s / 1e9, 2), "pcie_bound_frames_s": round(pcie_fps, 1),
+                      "frac_of_min_resident_pcie": round((n / dtu) / min(pcie_fps, resident_fps), 4),
+                      "equal_to_resident_pass": same}
+        del ou, imgs_pin
+
+    # additional leg (N = 1): a TUM sequence DIRECTORY -> matches (the reference's whole use case: main -> process_spacing ->
+    # extract(path) -> match, visualize_matches_sequence.py:272-357): sorted rgb/*.png -> PIL decode on a host thread pool ->
+    # pinned double buffer -> H2D on a side stream -> extract once -> all spacings.  Decode-inclusive, so host-bound.
+    dir_leg = None
+    if world == 1 and not args.no_directory:
+        import shutil
+        import tempfile
+
+        from sslam_amd.harness import run_directory
+        nd = min(n, args.tum_frames)
+        tmp = None
+        root = args.tum_root
+        if root is None or not os.path.isdir(root):
+            tmp = tempfile.mkdtemp(prefix="sslam_tum_")
+            root = os.path.join(tmp, "rgbd_dataset_synthetic")
+            synth.write_tum_rgb_sequence(root, imgs[:nd].cpu().numpy())
+            src = f"synthetic directory of the workload's first {nd} frames (no TUM data on this box)"
+        else:
+            src = f"{root} (first {nd} frames)"
+        try:
+            spac = (1, 5, 10, 15, 20)                       # visualize_matches_sequence.py:369
+            # tokens: the third-party ViT's output is an input here, as in `value` (real data would need real weights)
+            kw = dict(pipe=pipe, tokens_fn=(lambda a, b: toks[a:b]), max_frames=nd)
+            od = run_directory(root, "", spac, **kw)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            od = run_directory(root, "", spac, **kw)
+            torch.cuda.synchronize()
+            dtd = time.perf_counter() - td
+            nf = len(od["files"])
+            same = None
+            if tmp is not None:
+                same = bool(torch.equal(od[1]["matches"], out["matches"][:nf - 1]) and torch.equal(od[1]["match_count"], out["match_count"][:nf - 1]))
+            dir_leg = {"value": round(nf / dtd, 1), "unit": "frames/s", "frames": nf, "source": src, "spacings": list(spac),
+                       "pairs_matched": int(sum(od[s_]["match_count"].shape[0] for s_ in spac if s_ in od)),
+                       "what": "rgb/*.png -> PIL decode (thread pool) -> pinned double buffer -> H2D side stream -> A0..A9 once per frame -> "
+                               "M1 for every spacing; PNG decode on the host cores is the bound",
+                       "host_cpus": os.cpu_count(), "equal_to_resident_pass": same}
+            del od
+        finally:
+            if tmp is not None:
+                shutil.rmtree(tmp, ignore_errors=True)
+
     # additional leg (N = 1): BASELINE configs[1] "bf16 conv stack + fp32 matcher" - the same pass with the saliency CNN and
     # the descriptor MLP on bf16 MFMA.  Not index-exact, so it is never `value`: reported with its agreement rates against
     # the exact pass above on the same frames.
@@ -451,6 +535,10 @@ def main():
             res["latency"] = latency
         if bf16_leg is not None:
             res["bf16_mode"] = bf16_leg
+        if upload_leg is not None:
+            res["with_upload"] = upload_leg
+        if dir_leg is not None:
+            res["tum_directory"] = dir_leg
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
         if not ok:

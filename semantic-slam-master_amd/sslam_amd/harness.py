@@ -50,10 +50,16 @@ class SequenceMatcher:
 
 
 class StreamingSequence:
-    """Streaming pair scheduler.  Frames arrive in chunks (`push`); every frame is extracted once; a
-    ring of the last max(spacings) frames' descriptors / scores / intensities stays on the device, and each push
+    """Streaming pair scheduler.  Frames arrive in chunks (`push`); every frame is extracted once; each push
     matches, for every spacing s, exactly the pairs (j - s, j) whose SECOND frame j arrived in that push - so over a
     whole sequence every pair (i, i + s) is matched once, whatever the chunking.
+
+    Two storage modes:
+      * `reset(capacity=n)` (a sequence of known length; `run`, `run_frames`, `run_directory`): keypoints / descriptors /
+        scores / intensities of ALL n frames and the match arrays of every spacing live in sequence-sized device buffers
+        allocated once (613 frames x 264 KB = 162 MB - nothing beside 288 GB); every push writes its rows in place and the
+        matcher reads pair (i, i + s) by pointer offset: no ring, no concatenation, no copy;
+      * `reset()` (unbounded stream): a ring of the last max(spacings) frames' descriptors / scores / intensities.
 
     The reference's process_spacing (visualize_matches_sequence.py:298-300) visits only i = 0, s, 2s, ... and stops
     after `max_pairs` pairs: `reference_pairs()` selects those rows from the result."""
@@ -64,14 +70,56 @@ class StreamingSequence:
             raise ValueError("spacings must be positive")
         self.reset()
 
-    def reset(self):
+    def reset(self, capacity: int | None = None):
         self.n_seen = 0
-        self._ring = None        # dict of (r, ...) tensors: the last r <= max(spacings) frames
+        self.capacity = capacity
+        self._ring = None        # ring mode: dict of (r, ...) tensors, the last r <= max(spacings) frames
+        self._store = None       # capacity mode: extract buffers of `capacity` frames
+        self._pairs = {}         # capacity mode: spacing -> match buffers of (capacity - s) pairs
 
+    # ------------------------------------------------------------------------------------ capacity mode
+    def _push_in_place(self, tokens, images_u8):
+        pipe, m, n0 = self.pipe, tokens.shape[0], self.n_seen
+        if n0 + m > self.capacity:
+            raise ValueError(f"push past the declared capacity ({n0} + {m} > {self.capacity})")
+        if self._store is None:
+            self._store = pipe.alloc_extract(self.capacity, images_u8 is not None)
+            for s in self.spacings:
+                if self.capacity > s:
+                    self._pairs[s] = pipe.alloc_match(self.capacity - s)
+        st = self._store
+        pipe.extract(tokens, images_u8, out={k: v[n0:n0 + m] for k, v in st.items()})
+        res = {"frames": {k: v[n0:n0 + m] for k, v in st.items()}}
+        for s in self.spacings:
+            lo = max(n0, s) - s                                   # first pair whose second frame is new
+            cnt = n0 + m - s - lo
+            if cnt <= 0:
+                continue
+            mm = pipe.match(st["descriptors"][lo:lo + cnt + s], st["scores"][lo:lo + cnt + s],
+                            st["intensity"][lo:lo + cnt + s] if "intensity" in st else None, spacing=s,
+                            out={k: v[lo:lo + cnt] for k, v in self._pairs[s].items()})
+            mm["first"] = torch.arange(lo, lo + cnt, dtype=torch.int64, device=tokens.device)
+            res[s] = mm
+        self.n_seen += m
+        return res
+
+    def result(self) -> dict:
+        """Capacity mode: {'frames': ..., s: match dict with one row per pair (i, i + s) seen so far} - views, no copies."""
+        n = self.n_seen
+        res = {"frames": {k: v[:n] for k, v in (self._store or {}).items()}}
+        for s, bufs in self._pairs.items():
+            if n > s:
+                res[s] = {k: v[:n - s] for k, v in bufs.items()}
+                res[s]["first"] = torch.arange(0, n - s, dtype=torch.int64, device=bufs["quality"].device)
+        return res
+
+    # ---------------------------------------------------------------------------------------------- push
     def push(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
-        """Extract `tokens.shape[0]` new frames and match them against the ring.  Returns
+        """Extract `tokens.shape[0]` new frames and match them against the earlier ones.  Returns
         {'frames': extract dict of the new frames, s: {'first': global index of each pair's first frame (device int64),
         'matches', 'quality', 'match_count', ...}} for every spacing that has a pair ending in this chunk."""
+        if self.capacity is not None:
+            return self._push_in_place(tokens, images_u8)
         ex = self.pipe.extract(tokens, images_u8)
         m = tokens.shape[0]
         keys = ["descriptors", "scores"] + (["intensity"] if "intensity" in ex else [])
@@ -97,20 +145,174 @@ class StreamingSequence:
     def run(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None, chunk: int | None = None) -> dict:
         """Whole sequence: {'frames': ..., s: match dict with one row per pair (i, i + s), i = 0 .. n - s - 1}.
         chunk=None pushes everything at once; otherwise frames are pushed `chunk` at a time (same result)."""
-        self.reset()
         n = tokens.shape[0]
+        self.reset(capacity=n)
         step = n if chunk is None else int(chunk)
-        outs = [self.push(tokens[a:a + step], None if images_u8 is None else images_u8[a:a + step])
-                for a in range(0, n, step)]
-        res = {"frames": {k: torch.cat([o["frames"][k] for o in outs]) for k in outs[0]["frames"]}}
-        for s in self.spacings:
-            rows = [o[s] for o in outs if s in o]
-            if rows:
-                res[s] = {k: torch.cat([r_[k] for r_ in rows]) for k in rows[0]}
-        return res
+        for a in range(0, n, step):
+            self.push(tokens[a:a + step], None if images_u8 is None else images_u8[a:a + step])
+        return self.result()
 
     @staticmethod
     def reference_pairs(n_frames: int, spacing: int, max_pairs: int | None = None) -> list:
         """First-frame indices process_spacing visits: range(0, n - spacing, spacing), at most max_pairs of them."""
         idx = list(range(0, n_frames - spacing, spacing))
         return idx if max_pairs is None else idx[:max_pairs]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Host -> device feed.  The reference loads and uploads one frame at a time, synchronously
+# (visualize_matches_sequence.py:71-72).  Here chunk i + 1 is produced on the host (PNG decode on a thread pool, or a slice
+# of a host array) and uploaded on a side stream while chunk i is being extracted and matched.
+class FrameFeeder:
+    """Double-buffered upload of (n, H, W, 3) uint8 frames in chunks.
+
+    fill(host_rows: np.ndarray (m, H, W, 3) uint8 view of a PINNED buffer, a, b) writes frames [a, b) into host_rows
+    (called on a worker thread).  If `pinned_source` (a pinned (n, H, W, 3) uint8 torch tensor) is given instead, chunks
+    upload straight from it - no staging copy.  Iterating yields (a, b, device_images) with the upload of the NEXT chunk
+    already in flight; the device buffer of a chunk is reused two chunks later, after the compute stream has passed the
+    point where `release` was recorded (call `done(slot)` - or just keep iterating: it is recorded on the next __next__)."""
+
+    def __init__(self, n: int, h: int, w: int, device, bounds: list, fill=None, pinned_source: torch.Tensor | None = None):
+        if (fill is None) == (pinned_source is None):
+            raise ValueError("exactly one of fill / pinned_source")
+        self.n, self.h, self.w, self.device, self.bounds = n, h, w, torch.device(device), list(bounds)
+        self.fill, self.src = fill, pinned_source
+        cmax = max(b - a for a, b in self.bounds)
+        self.dev = [torch.empty((cmax, h, w, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.pin = None if fill is None else [torch.empty((cmax, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.uploaded = [None, None]          # event: H2D of the chunk in slot done (compute waits on it)
+        self.released = [None, None]          # event: compute finished with the slot's device buffer (copy waits on it)
+        self._pool = None
+        self._pending = {}
+
+    def _produce(self, i: int):
+        """Chunk i on the feeder thread: fill the pinned staging buffer (after the previous upload FROM it has completed),
+        then enqueue its upload on the copy stream (after the compute that last read the device buffer)."""
+        a, b = self.bounds[i]
+        slot = i & 1
+        if self.fill is not None:
+            ev = self.uploaded[slot]
+            if ev is not None:
+                ev.synchronize()
+            self.fill(self.pin[slot][: b - a].numpy(), a, b)
+        src = self.src[a:b] if self.src is not None else self.pin[slot][: b - a]
+        with torch.cuda.device(self.device), torch.cuda.stream(self.copy_stream):
+            if self.released[slot] is not None:
+                self.copy_stream.wait_event(self.released[slot])
+            self.dev[slot][: b - a].copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.uploaded[slot] = ev
+        return i
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        nb = len(self.bounds)
+        cur = torch.cuda.current_stream(self.device)
+        with ThreadPoolExecutor(max_workers=1) as feeder:
+            fut = feeder.submit(self._produce, 0) if nb else None
+            for i in range(nb):
+                fut.result()                                                             # chunk i is filled and its upload enqueued
+                # chunk i + 1 (the other slot) is produced and uploaded while the consumer works on chunk i; its device buffer
+                # was last read by chunk i - 1, whose release event was recorded at the end of the previous iteration
+                fut = feeder.submit(self._produce, i + 1) if i + 1 < nb else None
+                a, b = self.bounds[i]
+                slot = i & 1
+                cur.wait_event(self.uploaded[slot])
+                yield a, b, self.dev[slot][: b - a]
+                rel = torch.cuda.Event()
+                rel.record(cur)                                                          # the compute of chunk i is enqueued
+                self.released[slot] = rel
+
+
+def chunk_bounds(n: int, chunk: int, first: int | None = None) -> list:
+    """[a, b) chunk boundaries: an optional smaller first chunk (its upload is the only one that nothing overlaps)."""
+    out, a = [], 0
+    if first and first < chunk and n > first:
+        out.append((0, first))
+        a = first
+    while a < n:
+        out.append((a, min(a + chunk, n)))
+        a += chunk
+    return out
+
+
+@torch.no_grad()
+def run_frames(pipe: SequencePipeline, n: int, h: int, w: int, spacings=(1,), tokens: torch.Tensor | None = None, fill=None,
+               pinned_source: torch.Tensor | None = None, chunk: int | None = None, first_chunk: int | None = None) -> dict:
+    """Host-resident frames -> matches, with the upload of chunk i + 1 overlapping the compute of chunk i.
+    tokens: device-resident ViT tokens of the n frames (tokens-in mode); None: the pipeline's HIP ViT computes them
+    (pipe built with vit=).  Returns StreamingSequence.result() (sequence-sized buffers, written in place)."""
+    if tokens is None and pipe.vit_hip is None:
+        raise ValueError("tokens, or a pipeline built with vit=, required")
+    if chunk is None:
+        # ViT inside: whole launch groups of the ViT (82 frames at 448 x 448); tokens in: one round of the descriptor
+        # MLP's 768 workgroup slots (49 frames x 500 keypoints / 32 rows) - small enough that the first upload, which
+        # nothing overlaps, stays ~1 ms
+        chunk = pipe.vit_hip.chunk_frames(pipe.cfg.input_size) if tokens is None else max(1, (768 * 32) // pipe.cfg.num_keypoints)
+    seq = StreamingSequence(pipe, spacings)
+    seq.reset(capacity=n)
+    feeder = FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, first_chunk), fill=fill, pinned_source=pinned_source)
+    for a, b, img in feeder:
+        tk = tokens[a:b] if tokens is not None else pipe.tokens_from_images(img)
+        seq.push(tk, img)
+    return seq.result()
+
+
+def run_directory(root: str, sequence: str = "", spacings=(1, 5, 10, 15, 20), pipe: SequencePipeline | None = None,
+                  selector_state: dict | None = None, refiner_state: dict | None = None, cfg: ExtractorConfig | None = None,
+                  vit=None, tokens_fn=None, max_frames: int | None = None, chunk: int | None = None,
+                  decode_workers: int | None = None, device="cuda") -> dict:
+    """A TUM RGB-D sequence directory -> matches for every requested spacing: the batched counterpart of the reference's
+    main() -> process_spacing() -> extract(path) -> match loop (visualize_matches_sequence.py:272-357, 360-448) over the
+    directory layout of data/tum_dataset.py:210-224 (rgb/*.png sorted by name).
+
+    TUMSequence lists the frames; a thread pool decodes the PNGs of chunk i + 1 (PIL, 'RGB' as at :71) into a pinned
+    staging buffer while chunk i is uploaded on a side stream and extracted + matched on the compute stream.
+    Tokens come from the HIP ViT (`vit`: an sslam_amd.vit.DinoV3ViT holding the weights) or from `tokens_fn(a, b) ->
+    (b - a, 5 + G^2, 384) device tensor` (any other backbone).  Returns StreamingSequence.result() plus 'files'."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image
+
+    from .tum import TUMSequence
+    tum = TUMSequence(root, sequence, max_frames=max_frames)
+    n = len(tum)
+    if n == 0:
+        raise ValueError(f"no rgb frames under {tum.rgb_dir}")
+    if pipe is None:
+        pipe = SequencePipeline(cfg or ExtractorConfig(), selector_state, refiner_state, device=device, vit=vit)
+    if tokens_fn is None and pipe.vit_hip is None:
+        raise ValueError("vit= (HIP ViT) or tokens_fn required")
+    with Image.open(tum.rgb_path(0)) as im0:
+        w, h = im0.size
+    workers = decode_workers or max(1, min(16, (os.cpu_count() or 2) - 1))
+    pool = ThreadPoolExecutor(max_workers=workers)
+
+    def decode(i, dst):
+        with Image.open(tum.rgb_path(i)) as im:
+            arr = np.asarray(im.convert("RGB"))
+        if arr.shape != dst.shape:
+            raise ValueError(f"{tum.rgb_files[i]}: {arr.shape[:2]} differs from the first frame's {(h, w)}")
+        dst[...] = arr
+
+    def fill(host_rows, a, b):
+        list(pool.map(lambda j: decode(a + j, host_rows[j]), range(b - a)))
+
+    if chunk is None:
+        chunk = pipe.vit_hip.chunk_frames(pipe.cfg.input_size) if tokens_fn is None else 64
+    seq = StreamingSequence(pipe, spacings)
+    seq.reset(capacity=n)
+    try:
+        with torch.no_grad():
+            for a, b, img in FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, min(chunk, 16)), fill=fill):
+                tk = tokens_fn(a, b) if tokens_fn is not None else pipe.tokens_from_images(img)
+                seq.push(tk, img)
+    finally:
+        pool.shutdown(wait=True)
+    res = seq.result()
+    res["files"] = list(tum.rgb_files)
+    res["timestamps"] = list(tum.timestamps)
+    return res

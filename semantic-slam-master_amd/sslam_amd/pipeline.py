@@ -289,8 +289,17 @@ class SequencePipeline:
             th, tv = self.tables.get(h, w, cfg.input_size, True)
             lib.keypoint_intensity(images_u8, cfg.input_size, th, tv, out["keypoints_pixel"], out=out["intensity"])
 
-    def match(self, desc, scores, intensity=None, spacing: int | None = None, halo: dict | None = None) -> dict:
-        """M1 for all pairs (i, i + spacing) inside the batch.  desc (N, K, 128), scores (N, K), intensity (N, K)."""
+    def alloc_match(self, n_pairs: int, k: int | None = None) -> dict:
+        """Output buffers of match() for n_pairs pairs (fixed capacity K per pair + device-side count)."""
+        k = self.cfg.num_keypoints if k is None else k
+        dev = self.device
+        return dict(matches=torch.empty((n_pairs, k, 2), dtype=torch.int64, device=dev),
+                    quality=torch.empty((n_pairs, k), dtype=torch.float32, device=dev),
+                    match_count=torch.empty((n_pairs,), dtype=torch.int32, device=dev))
+
+    def match(self, desc, scores, intensity=None, spacing: int | None = None, out: dict | None = None) -> dict:
+        """M1 for all pairs (i, i + spacing) inside the batch.  desc (N, K, 128), scores (N, K), intensity (N, K).
+        out: row slices of alloc_match buffers to write into (the streaming scheduler passes slices of sequence-sized ones)."""
         cfg = self.cfg
         sp = cfg.spacing if spacing is None else spacing
         n, k = desc.shape[0], desc.shape[1]
@@ -301,10 +310,7 @@ class SequencePipeline:
                         quality=z((0, k), dtype=torch.float32, device=desc.device),
                         match_count=z((0,), dtype=torch.int32, device=desc.device))
         use_int = cfg.use_intensity and intensity is not None
-        dev = desc.device
-        res = dict(matches=torch.empty((n_pairs, k, 2), dtype=torch.int64, device=dev),
-                   quality=torch.empty((n_pairs, k), dtype=torch.float32, device=dev),
-                   match_count=torch.empty((n_pairs,), dtype=torch.int32, device=dev))
+        res = dict(out) if out is not None else self.alloc_match(n_pairs, k)
         aux = []
         for a in range(0, n_pairs, MAX_PAIRS_PER_LAUNCH):       # the pair index is a 16-bit grid dimension
             m = min(MAX_PAIRS_PER_LAUNCH, n_pairs - a)

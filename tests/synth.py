@@ -213,3 +213,27 @@ def write_tum_sequence(root, n_rgb: int = 9, n_depth: int = 7, n_gt: int = 11) -
             f.write(f"{1305031451.7 + 0.41 * k:.4f} {0.1 * k:.4f} {-0.05 * k:.4f} {1.0 + 0.01 * k:.4f} "
                     f"{q[0]:.6f} {q[1]:.6f} {q[2]:.6f} {q[3]:.6f}\n")
     return names
+
+
+def write_tum_rgb_sequence(root, frames: np.ndarray, with_depth: bool = False) -> list:
+    """A TUM-layout sequence directory whose rgb/ frames are `frames` ((n, H, W, 3) uint8), named by 30 Hz timestamps in
+    the TUM style (files are written in a scrambled order: the reader must sort by name); groundtruth.txt with one pose per
+    frame.  For the directory -> matches tests and `bench.py --tum-root` when no real sequence is on the box."""
+    import os
+
+    from PIL import Image
+    os.makedirs(os.path.join(root, "rgb"), exist_ok=True)
+    n = len(frames)
+    names = [f"{1305031452 + (791720 + 33333 * i) // 1000000}.{(791720 + 33333 * i) % 1000000:06d}.png" for i in range(n)]
+    assert names == sorted(names)
+    for i in _rng(81_000).permutation(n):
+        Image.fromarray(frames[i]).save(os.path.join(root, "rgb", names[i]), compress_level=1)
+    if with_depth:
+        os.makedirs(os.path.join(root, "depth"), exist_ok=True)
+        for i in range(n):
+            Image.fromarray(depth(i, frames.shape[1], frames.shape[2])).save(os.path.join(root, "depth", names[i]))
+    with open(os.path.join(root, "groundtruth.txt"), "w") as f:
+        f.write("# timestamp tx ty tz qx qy qz qw\n")
+        for i in range(n):
+            f.write(f"{1305031452.7917 + i / 30.0:.4f} {0.01 * i:.4f} 0.0000 1.0000 0.000000 0.000000 0.000000 1.000000\n")
+    return names
