@@ -340,6 +340,13 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const int *__restri
         __syncthreads();
     }
     if (tid == 0) count[p] = running;
+    // slots past the count are zeroed, so that the fixed-capacity arrays are a pure function of the inputs (whole-array
+    // comparisons across chunkings / ranks hold; the reference's arrays simply end at the count)
+    for (int sl = running + tid; sl < n1; sl += 256) {
+        matches[2 * sl] = 0;
+        matches[2 * sl + 1] = 0;
+        quality[sl] = 0.f;
+    }
 }
 
 }  // namespace

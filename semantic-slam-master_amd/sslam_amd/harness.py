@@ -78,7 +78,7 @@ class StreamingSequence:
         self._pairs = {}         # capacity mode: spacing -> match buffers of (capacity - s) pairs
 
     # ------------------------------------------------------------------------------------ capacity mode
-    def _push_in_place(self, tokens, images_u8):
+    def _push_in_place(self, tokens, images_u8, images_ready=None):
         pipe, m, n0 = self.pipe, tokens.shape[0], self.n_seen
         if n0 + m > self.capacity:
             raise ValueError(f"push past the declared capacity ({n0} + {m} > {self.capacity})")
@@ -88,7 +88,7 @@ class StreamingSequence:
                 if self.capacity > s:
                     self._pairs[s] = pipe.alloc_match(self.capacity - s)
         st = self._store
-        pipe.extract(tokens, images_u8, out={k: v[n0:n0 + m] for k, v in st.items()})
+        pipe.extract(tokens, images_u8, out={k: v[n0:n0 + m] for k, v in st.items()}, images_ready=images_ready)
         res = {"frames": {k: v[n0:n0 + m] for k, v in st.items()}}
         for s in self.spacings:
             lo = max(n0, s) - s                                   # first pair whose second frame is new
@@ -114,13 +114,15 @@ class StreamingSequence:
         return res
 
     # ---------------------------------------------------------------------------------------------- push
-    def push(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None) -> dict:
+    def push(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None, images_ready=None) -> dict:
         """Extract `tokens.shape[0]` new frames and match them against the earlier ones.  Returns
         {'frames': extract dict of the new frames, s: {'first': global index of each pair's first frame (device int64),
-        'matches', 'quality', 'match_count', ...}} for every spacing that has a pair ending in this chunk."""
+        'matches', 'quality', 'match_count', ...}} for every spacing that has a pair ending in this chunk.
+        images_ready: event of an upload of images_u8 still in flight (SequencePipeline.extract waits for it only in front
+        of the first kernel that reads pixels)."""
         if self.capacity is not None:
-            return self._push_in_place(tokens, images_u8)
-        ex = self.pipe.extract(tokens, images_u8)
+            return self._push_in_place(tokens, images_u8, images_ready)
+        ex = self.pipe.extract(tokens, images_u8, images_ready=images_ready)
         m = tokens.shape[0]
         keys = ["descriptors", "scores"] + (["intensity"] if "intensity" in ex else [])
         cat = {k: (ex[k] if self._ring is None else torch.cat([self._ring[k], ex[k]])) for k in keys}
@@ -164,66 +166,113 @@ class StreamingSequence:
 # (visualize_matches_sequence.py:71-72).  Here chunk i + 1 is produced on the host (PNG decode on a thread pool, or a slice
 # of a host array) and uploaded on a side stream while chunk i is being extracted and matched.
 class FrameFeeder:
-    """Double-buffered upload of (n, H, W, 3) uint8 frames in chunks.
+    """Chunked upload of (n, H, W, 3) uint8 frames on a side stream, running AHEAD of the compute.
 
-    fill(host_rows: np.ndarray (m, H, W, 3) uint8 view of a PINNED buffer, a, b) writes frames [a, b) into host_rows
-    (called on a worker thread).  If `pinned_source` (a pinned (n, H, W, 3) uint8 torch tensor) is given instead, chunks
-    upload straight from it - no staging copy.  Iterating yields (a, b, device_images) with the upload of the NEXT chunk
-    already in flight; the device buffer of a chunk is reused two chunks later, after the compute stream has passed the
-    point where `release` was recorded (call `done(slot)` - or just keep iterating: it is recorded on the next __next__)."""
+    fill(host_rows: np.ndarray (m, H, W, 3) uint8 view of a PINNED staging buffer, a, b) writes frames [a, b) into
+    host_rows (called on the feeder thread).  If `pinned_source` (a pinned (n, H, W, 3) uint8 torch tensor) is given
+    instead, chunks upload straight from it - no staging copy.
 
-    def __init__(self, n: int, h: int, w: int, device, bounds: list, fill=None, pinned_source: torch.Tensor | None = None):
+    Device side: HBM is sized for whole sequences (613 frames = 565 MB, 2 585 = 2.4 GB of 288 GB), so by default every
+    chunk uploads into ITS rows of one sequence-sized device buffer: no slot is ever reused, the uploads never wait for
+    the compute and stream back to back at the PCIe rate while the compute follows one chunk behind.  Above `max_bytes`
+    (long or unbounded sequences) the device buffer is a ring of `ring` chunk slots, each reused only after the compute
+    that read it has passed (release events).  Iterating yields (a, b, device_images, ready): `ready` is the event of
+    the chunk's upload - the CONSUMER makes its stream wait for it, in front of the first kernel that reads pixels."""
+
+    _cache: dict = {}      # (device, shape) -> device buffer kept between sequences (a 565 MB hipMalloc costs milliseconds)
+
+    def __init__(self, n: int, h: int, w: int, device, bounds: list, fill=None, pinned_source: torch.Tensor | None = None,
+                 max_bytes: int = 16 << 30, ring: int = 4):
         if (fill is None) == (pinned_source is None):
             raise ValueError("exactly one of fill / pinned_source")
         self.n, self.h, self.w, self.device, self.bounds = n, h, w, torch.device(device), list(bounds)
         self.fill, self.src = fill, pinned_source
         cmax = max(b - a for a, b in self.bounds)
-        self.dev = [torch.empty((cmax, h, w, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
-        self.pin = None if fill is None else [torch.empty((cmax, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(self.device)
-        self.uploaded = [None, None]          # event: H2D of the chunk in slot done (compute waits on it)
-        self.released = [None, None]          # event: compute finished with the slot's device buffer (copy waits on it)
-        self._pool = None
-        self._pending = {}
+        nb = len(self.bounds)
+        self.whole = n * h * w * 3 <= max_bytes
+        self.n_slots = nb if self.whole else min(ring, nb)
+        shape = (n, h, w, 3) if self.whole else (self.n_slots, cmax, h, w, 3)
+        key = (str(self.device), "dev")
+        buf = FrameFeeder._cache.get(key)
+        numel = int(np.prod(shape))
+        if buf is None or buf.numel() < numel:
+            buf = FrameFeeder._cache[key] = torch.empty(numel, dtype=torch.uint8, device=self.device)
+        self.dev = buf[:numel].view(shape)
+        self.pin = None
+        if fill is not None:
+            pkey, pn = (str(self.device), "pin"), 2 * cmax * h * w * 3
+            pbuf = FrameFeeder._cache.get(pkey)
+            if pbuf is None or pbuf.numel() < pn:
+                pbuf = FrameFeeder._cache[pkey] = torch.empty(pn, dtype=torch.uint8).pin_memory()
+            self.pin = [pbuf[i * (pn // 2):(i + 1) * (pn // 2)].view(cmax, h, w, 3) for i in range(2)]
+        skey = (str(self.device), "stream")
+        if skey not in FrameFeeder._cache:
+            FrameFeeder._cache[skey] = torch.cuda.Stream(self.device)
+        self.copy_stream = FrameFeeder._cache[skey]
+        self.uploaded = [None] * nb                  # event per chunk: its H2D is complete (the compute waits on it)
+        self.released = [None] * self.n_slots        # ring mode: the compute has finished with the slot (the copy waits on it)
+        self.staged = [None, None]                   # event per staging buffer: the last upload FROM it is complete
 
-    def _produce(self, i: int):
-        """Chunk i on the feeder thread: fill the pinned staging buffer (after the previous upload FROM it has completed),
-        then enqueue its upload on the copy stream (after the compute that last read the device buffer)."""
+    def _view(self, i: int):
         a, b = self.bounds[i]
-        slot = i & 1
-        if self.fill is not None:
-            ev = self.uploaded[slot]
-            if ev is not None:
-                ev.synchronize()
-            self.fill(self.pin[slot][: b - a].numpy(), a, b)
-        src = self.src[a:b] if self.src is not None else self.pin[slot][: b - a]
+        return self.dev[a:b] if self.whole else self.dev[i % self.n_slots][: b - a]
+
+    def _enqueue_upload(self, i: int, src: torch.Tensor):
+        """H2D of chunk i on the copy stream (ring mode: after the compute that last read the device slot) + its event."""
         with torch.cuda.device(self.device), torch.cuda.stream(self.copy_stream):
-            if self.released[slot] is not None:
-                self.copy_stream.wait_event(self.released[slot])
-            self.dev[slot][: b - a].copy_(src, non_blocking=True)
+            if not self.whole:
+                rel = self.released[i % self.n_slots]
+                if rel is not None:
+                    self.copy_stream.wait_event(rel)
+            self._view(i).copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
-        self.uploaded[slot] = ev
+        self.uploaded[i] = ev
+        return ev
+
+    def _produce(self, i: int):
+        """fill mode, chunk i on the feeder thread: fill the pinned staging buffer (after the previous upload FROM it has
+        completed - PIL decode and numpy copies release the GIL), then enqueue its upload."""
+        a, b = self.bounds[i]
+        ps = i & 1
+        if self.staged[ps] is not None:
+            self.staged[ps].synchronize()
+        self.fill(self.pin[ps][: b - a].numpy(), a, b)
+        self.staged[ps] = self._enqueue_upload(i, self.pin[ps][: b - a])
         return i
 
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
         nb = len(self.bounds)
         cur = torch.cuda.current_stream(self.device)
-        with ThreadPoolExecutor(max_workers=1) as feeder:
-            fut = feeder.submit(self._produce, 0) if nb else None
+        self.copy_stream.wait_stream(cur)              # the device buffer may still be read by earlier work of the caller
+        # how far the uploads may run ahead of the consumer: everything (whole-sequence buffer) or the free ring slots
+        ahead = nb if self.whole else self.n_slots - 1
+        # a pinned source needs no host work: the CALLING thread enqueues the copies (a helper thread would wait for the GIL
+        # behind the launch loop - measured: uploads enqueued milliseconds late); a `fill` source decodes on a feeder thread
+        feeder = ThreadPoolExecutor(max_workers=1) if self.fill is not None else None
+        try:
+            futs, nxt = {}, 0
             for i in range(nb):
-                fut.result()                                                             # chunk i is filled and its upload enqueued
-                # chunk i + 1 (the other slot) is produced and uploaded while the consumer works on chunk i; its device buffer
-                # was last read by chunk i - 1, whose release event was recorded at the end of the previous iteration
-                fut = feeder.submit(self._produce, i + 1) if i + 1 < nb else None
+                while nxt < nb and nxt <= i + ahead:
+                    # ring mode: the slot of chunk nxt was last read by chunk nxt - n_slots <= i - 1, released below
+                    if feeder is not None:
+                        futs[nxt] = feeder.submit(self._produce, nxt)
+                    else:
+                        a, b = self.bounds[nxt]
+                        self._enqueue_upload(nxt, self.src[a:b])
+                    nxt += 1
+                if feeder is not None:
+                    futs.pop(i).result()                  # chunk i is filled and its upload enqueued
                 a, b = self.bounds[i]
-                slot = i & 1
-                cur.wait_event(self.uploaded[slot])
-                yield a, b, self.dev[slot][: b - a]
-                rel = torch.cuda.Event()
-                rel.record(cur)                                                          # the compute of chunk i is enqueued
-                self.released[slot] = rel
+                yield a, b, self._view(i), self.uploaded[i]
+                if not self.whole:
+                    rel = torch.cuda.Event()
+                    rel.record(cur)                       # the compute of chunk i is enqueued
+                    self.released[i % self.n_slots] = rel
+        finally:
+            if feeder is not None:
+                feeder.shutdown(wait=True)
 
 
 def chunk_bounds(n: int, chunk: int, first: int | None = None) -> list:
@@ -240,23 +289,37 @@ def chunk_bounds(n: int, chunk: int, first: int | None = None) -> list:
 
 @torch.no_grad()
 def run_frames(pipe: SequencePipeline, n: int, h: int, w: int, spacings=(1,), tokens: torch.Tensor | None = None, fill=None,
-               pinned_source: torch.Tensor | None = None, chunk: int | None = None, first_chunk: int | None = None) -> dict:
+               pinned_source: torch.Tensor | None = None, chunk: int | None = None, first_chunk: int | None = None,
+               preprocess_too: bool = False, feeder_kw: dict | None = None) -> dict:
     """Host-resident frames -> matches, with the upload of chunk i + 1 overlapping the compute of chunk i.
     tokens: device-resident ViT tokens of the n frames (tokens-in mode); None: the pipeline's HIP ViT computes them
-    (pipe built with vit=).  Returns StreamingSequence.result() (sequence-sized buffers, written in place)."""
+    (pipe built with vit=).  preprocess_too: in tokens-in mode also run A0 on every chunk (the ViT input a real backbone would
+    consume; bench.py counts it in `value`).  Returns StreamingSequence.result() (sequence-sized buffers, written in place)."""
     if tokens is None and pipe.vit_hip is None:
         raise ValueError("tokens, or a pipeline built with vit=, required")
     if chunk is None:
-        # ViT inside: whole launch groups of the ViT (82 frames at 448 x 448); tokens in: one round of the descriptor
-        # MLP's 768 workgroup slots (49 frames x 500 keypoints / 32 rows) - small enough that the first upload, which
-        # nothing overlaps, stays ~1 ms
-        chunk = pipe.vit_hip.chunk_frames(pipe.cfg.input_size) if tokens is None else max(1, (768 * 32) // pipe.cfg.num_keypoints)
+        # ViT inside: whole launch groups of the ViT (82 frames at 448 x 448) - every stage needs the pixels, but the ViT
+        # dwarfs the upload.  Tokens in: A2..A7 of a chunk read only tokens and run while ITS pixels are still uploading, so
+        # large chunks win (fewer partial rounds of tiles, tools/upload_sweep.py: 613 frames in chunks of 83 / 167 / 307 /
+        # 613 -> 47.8 / 51.6 / 54.5 / 55.8 k frames/s): half the sequence, within one launch group
+        if tokens is None:
+            chunk = pipe.vit_hip.chunk_frames(pipe.cfg.input_size)
+        else:
+            chunk = max(1, min(pipe.launch_group(), max((n + 1) // 2, (1024 * 128) // pipe.cfg.grid ** 2)))
     seq = StreamingSequence(pipe, spacings)
     seq.reset(capacity=n)
-    feeder = FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, first_chunk), fill=fill, pinned_source=pinned_source)
-    for a, b, img in feeder:
-        tk = tokens[a:b] if tokens is not None else pipe.tokens_from_images(img)
-        seq.push(tk, img)
+    feeder = FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, first_chunk), fill=fill, pinned_source=pinned_source,
+                         **(feeder_kw or {}))
+    cur = torch.cuda.current_stream(pipe.device)
+    for a, b, img, ready in feeder:
+        if tokens is not None:
+            # the pixels are first read by A9, the last stage of the extraction: A2..A7 run while the upload is in flight
+            seq.push(tokens[a:b], img, images_ready=ready)
+            if preprocess_too:
+                pipe.preprocess(img)
+        else:
+            cur.wait_event(ready)
+            seq.push(pipe.tokens_from_images(img), img)
     return seq.result()
 
 
@@ -307,9 +370,13 @@ def run_directory(root: str, sequence: str = "", spacings=(1, 5, 10, 15, 20), pi
     seq.reset(capacity=n)
     try:
         with torch.no_grad():
-            for a, b, img in FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, min(chunk, 16)), fill=fill):
-                tk = tokens_fn(a, b) if tokens_fn is not None else pipe.tokens_from_images(img)
-                seq.push(tk, img)
+            cur = torch.cuda.current_stream(pipe.device)
+            for a, b, img, ready in FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, min(chunk, 16)), fill=fill):
+                if tokens_fn is not None:
+                    seq.push(tokens_fn(a, b), img, images_ready=ready)
+                else:
+                    cur.wait_event(ready)
+                    seq.push(pipe.tokens_from_images(img), img)
     finally:
         pool.shutdown(wait=True)
     res = seq.result()

@@ -252,23 +252,28 @@ class SequencePipeline:
             out["intensity"] = torch.empty((n, K), **f32)
         return out
 
-    def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None, out: dict | None = None) -> dict:
+    def extract(self, tokens: torch.Tensor, images_u8: torch.Tensor | None = None, out: dict | None = None,
+                images_ready: "torch.cuda.Event | None" = None) -> dict:
         """A2..A9 for any number of frames (launch groups of `launch_group()` frames).  Returns device tensors; no host
         synchronisation unless num_keypoints exceeds the number of grid cells (the only case `status` can be set).
         out: buffers from alloc_extract (or row slices of them) to write into - the sharded runner and the streaming
-        scheduler pass slices of sequence-sized buffers, so nothing is copied afterwards."""
+        scheduler pass slices of sequence-sized buffers, so nothing is copied afterwards.
+        images_ready: event after which images_u8 holds the frames (an upload in flight on another stream): the current
+        stream waits for it in front of the FIRST kernel that reads pixels - A9, the last stage - so A2..A7, which read
+        only the tokens, run while the upload is still in flight."""
         n, step = tokens.shape[0], self.launch_group()
         if out is None:
             out = self.alloc_extract(n, images_u8 is not None)
         for a in range(0, n, step):
             b = min(a + step, n)
-            self._extract_group(tokens[a:b], None if images_u8 is None else images_u8[a:b], {k: v[a:b] for k, v in out.items()})
+            self._extract_group(tokens[a:b], None if images_u8 is None else images_u8[a:b], {k: v[a:b] for k, v in out.items()},
+                                images_ready if a == 0 else None)
         if self.cfg.num_keypoints > self.cfg.grid ** 2 and bool(out["status"].any()):
             # torch.topk raises there in the reference (keypoint_selector.py:160 / :176, SURVEY H6)
             raise RuntimeError("selected index k out of range")
         return out
 
-    def _extract_group(self, tokens: torch.Tensor, images_u8: torch.Tensor | None, out: dict) -> None:
+    def _extract_group(self, tokens: torch.Tensor, images_u8: torch.Tensor | None, out: dict, images_ready=None) -> None:
         cfg, s = self.cfg, self.selector
         ws = self.workspace(tokens.shape[0], 0)
         if self.bf16:
@@ -284,6 +289,8 @@ class SequencePipeline:
             lib.gather_refine_bf16(feat, out["keypoints_patch"], self.refiner.packed_bf16, self.refiner.n_blocks, out=out["descriptors"])
         else:
             lib.gather_refine(feat, out["keypoints_patch"], self.refiner.packed, self.refiner.n_blocks, out=out["descriptors"])
+        if images_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(images_ready)
         if images_u8 is not None and "intensity" in out:
             n, h, w, _ = images_u8.shape
             th, tv = self.tables.get(h, w, cfg.input_size, True)

@@ -169,6 +169,13 @@ def test_run_directory_equals_resident_run(T, pipe, tmp_path):
                      fill=lambda dst, a, b: np.copyto(dst, imgs_h[a:b]))
     _assert_same(T, got[1], one, ("matches", "quality", "match_count"))
     _assert_same(T, got["frames"], one, ("idx", "descriptors", "intensity"))
+    # long / unbounded sequences: the device side is a ring of chunk slots reused behind the compute (release events)
+    for kw in (dict(pinned_source=pinned), dict(fill=lambda dst, a, b: np.copyto(dst, imgs_h[a:b]))):
+        got = run_frames(pipe, n, 480, 640, spacings=(1, 5), tokens=toks, chunk=3, first_chunk=1, preprocess_too=True,
+                         feeder_kw=dict(max_bytes=0, ring=3), **kw)
+        _assert_same(T, got[1], one, ("matches", "quality", "match_count"))
+        _assert_same(T, got[5], want[5], ("matches", "quality", "match_count"))
+        _assert_same(T, got["frames"], one, ("idx", "descriptors", "intensity"))
 
 
 def test_run_directory_with_the_hip_vit(T, tmp_path):
