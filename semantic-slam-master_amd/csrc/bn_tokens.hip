@@ -125,77 +125,168 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
     }
 }
 
-// Register-resident form for group == 1 and cells <= 16 * NR (G = 28: 784 cells = 16 x 49): the three sweeps of the
-// kernel above re-read the tokens from MALL/HBM (a CU's resident workgroups cover far more than its L2 share), which
-// makes that kernel bandwidth-bound at 3x the compulsory read traffic.  Here every lane keeps its NR rows (float4 each)
-// in VGPRs between the sweeps: one HBM read, one write.  Same partition and summation order, bit-identical results.
+// Register-resident form for group == 1: the three sweeps of the kernel above re-read the tokens from MALL/HBM (a CU's
+// resident workgroups cover far more than its L2 share), which makes that kernel bandwidth-bound at 3x the compulsory read
+// traffic.  Here every lane keeps its rows in VGPRs (and, for the largest grids, the last NL row steps in LDS) between the
+// sweeps: one HBM read, one write.  Same partition (16 partials by row & 15, each a sequential sum in row order) and the
+// same combination tree as the sweep kernel, so the results are bit-identical.
+//   V  = channels per lane (4: a workgroup owns 64 channels, 2: 32 channels; 16 lanes x V x 4 B is one 256 / 128-byte row
+//        segment per wave-quarter, always whole cache lines)
+//   NR = row steps (of 16 rows) held in registers, NL = further row steps held in LDS; cells <= 16 * (NR + NL)
+//   G = 28: <4, 49, 0>, two workgroups per CU.  G = 40 (1 600 cells): <4, 100, 0> = 400 VGPRs, one wave per SIMD - a lane
+//   has 100 independent 16-byte loads in flight, which is all the latency hiding a streaming kernel needs.  G = 60 (3 600
+//   cells): a 64-channel slice is 921 KB, more than a CU's 512 KB of VGPRs: <2, 200, 25> keeps a 32-channel slice in 400
+//   VGPRs + 51 KB of LDS.
 // Addresses are one uniform base per row step plus a 32-bit lane offset (no per-row address registers).
-template <int NR>
-__global__ __launch_bounds__(256, 2) void bn_tokens_reg_kernel(const float *__restrict__ tokens, int tokens_per_frame,
-                                                                int n_prefix, const float *__restrict__ gamma,
-                                                                const float *__restrict__ beta, float eps,
-                                                                float *__restrict__ out_feat, float *__restrict__ out_mean,
-                                                                float *__restrict__ out_var, uint2 *__restrict__ out_bf16) {
+template <int V>
+struct VecT;
+template <>
+struct VecT<4> { typedef float4 T; };
+template <>
+struct VecT<2> { typedef float2 T; };
+
+template <int V>
+__device__ __forceinline__ void comb16v(const float (&v)[V], float (&t)[V], float (*sh)[64], int wave, int lane) {
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        s[j] = v[j] + __shfl_xor(v[j], 16);
+        s[j] = s[j] + __shfl_xor(s[j], 32);
+    }
+    __syncthreads();  // previous use of sh is over
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < V; j++) sh[wave][V * lane + j] = s[j];
+    }
+    __syncthreads();
+    const int c = V * (lane & 15);
+#pragma unroll
+    for (int j = 0; j < V; j++) t[j] = ((sh[0][c + j] + sh[1][c + j]) + sh[2][c + j]) + sh[3][c + j];
+}
+
+template <int V, int NR, int NL, int WPS>
+__global__ __launch_bounds__(256, WPS) void bn_tokens_reg_kernel(const float *__restrict__ tokens, int tokens_per_frame,
+                                                                  int n_prefix, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float eps,
+                                                                  float *__restrict__ out_feat, float *__restrict__ out_mean,
+                                                                  float *__restrict__ out_var, unsigned *__restrict__ out_bf16) {
+    typedef typename VecT<V>::T vec;
     __shared__ float sh[4][64];
+    __shared__ vec hold[NL > 0 ? NL : 1][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, ch0 = blockIdx.y * 64 + 4 * (lane & 15);
+    const int g = blockIdx.x, ch0 = blockIdx.y * (16 * V) + V * (lane & 15);
     const int R = tokens_per_frame - n_prefix;
     const int p = 4 * wave + (lane >> 4);
     const int full = R / 16, rem = R % 16;          // row steps valid for every lane / lanes valid in step `full`
     const float *src = tokens + ((long long)g * tokens_per_frame + n_prefix) * SSLAM_C;     // uniform
     const unsigned loff = (unsigned)(p * SSLAM_C + ch0);                                    // per lane, floats
-    float4 x[NR];
+    auto valid = [&](int i) { return i < full || (i == full && p < rem); };
+    float x[NR][V];
+    if (NL > 0) {
+        vec t[NL > 0 ? NL : 1];                 // all NL loads in flight together, then the LDS stores
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            t[i] = vec{};
+            if (valid(NR + i)) t[i] = *reinterpret_cast<const vec *>(src + (size_t)(NR + i) * 16 * SSLAM_C + loff);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) hold[i][tid] = t[i];      // own slots only: no barrier between these stores and the loads below
+    }
 #pragma unroll
     for (int i = 0; i < NR; i++) {
-        x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < full || (i == full && p < rem)) x[i] = *reinterpret_cast<const float4 *>(src + (size_t)i * 16 * SSLAM_C + loff);
+        vec v = {};
+        if (valid(i)) v = *reinterpret_cast<const vec *>(src + (size_t)i * 16 * SSLAM_C + loff);
+#pragma unroll
+        for (int j = 0; j < V; j++) x[i][j] = reinterpret_cast<const float *>(&v)[j];
     }
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s[V], tot[V], mean[V], var[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) s[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < NR; i++)
-        if (i < full || (i == full && p < rem)) { s.x = s.x + x[i].x; s.y = s.y + x[i].y; s.z = s.z + x[i].z; s.w = s.w + x[i].w; }
-    const float4 tot = comb16(s, sh, wave, lane);
-    const float fr = (float)R;
-    const float4 mean = make_float4(tot.x / fr, tot.y / fr, tot.z / fr, tot.w / fr);
-    s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid(i)) {
 #pragma unroll
-    for (int i = 0; i < NR; i++)
-        if (i < full || (i == full && p < rem)) {
-            const float dx = x[i].x - mean.x, dy = x[i].y - mean.y, dz = x[i].z - mean.z, dw = x[i].w - mean.w;
-            s.x = __builtin_fmaf(dx, dx, s.x); s.y = __builtin_fmaf(dy, dy, s.y);
-            s.z = __builtin_fmaf(dz, dz, s.z); s.w = __builtin_fmaf(dw, dw, s.w);
+            for (int j = 0; j < V; j++) s[j] = s[j] + x[i][j];
         }
-    const float4 tot2 = comb16(s, sh, wave, lane);
-    const float4 var = make_float4(tot2.x / fr, tot2.y / fr, tot2.z / fr, tot2.w / fr);
-    if (tid < 16) {
-        if (out_mean) *reinterpret_cast<float4 *>(out_mean + (long long)g * SSLAM_C + ch0) = mean;
-        if (out_var) *reinterpret_cast<float4 *>(out_var + (long long)g * SSLAM_C + ch0) = var;
-    }
-    const float4 ga = *reinterpret_cast<const float4 *>(gamma + ch0);
-    const float4 be = *reinterpret_cast<const float4 *>(beta + ch0);
-    float4 al, bs;
-    al.x = (1.0f / sqrtf(var.x + eps)) * ga.x; al.y = (1.0f / sqrtf(var.y + eps)) * ga.y;
-    al.z = (1.0f / sqrtf(var.z + eps)) * ga.z; al.w = (1.0f / sqrtf(var.w + eps)) * ga.w;
-    bs.x = be.x - mean.x * al.x; bs.y = be.y - mean.y * al.y;
-    bs.z = be.z - mean.z * al.z; bs.w = be.w - mean.w * al.w;
-    float *dst = out_feat + (long long)g * R * SSLAM_C;                                      // uniform
-    uint2 *dst_bf = out_bf16 ? out_bf16 + (long long)g * R * (SSLAM_C / 4) : nullptr;
+    if (NL > 0) {
 #pragma unroll
-    for (int i = 0; i < NR; i++)
-        if (i < full || (i == full && p < rem)) {
-            float4 y;
-            y.x = x[i].x * al.x + bs.x; y.y = x[i].y * al.y + bs.y; y.z = x[i].z * al.z + bs.z; y.w = x[i].w * al.w + bs.w;
-            *reinterpret_cast<float4 *>(dst + (size_t)i * 16 * SSLAM_C + loff) = y;
-            if (dst_bf) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                const f32x2 lo = {y.x, y.y}, hi = {y.z, y.w};
-                uint2 o;
-                o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-                o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-                dst_bf[(size_t)i * 16 * (SSLAM_C / 4) + loff / 4] = o;
+        for (int i = NR; i < NR + NL; i++)
+            if (valid(i)) {
+                const vec v = hold[i - NR][tid];
+#pragma unroll
+                for (int j = 0; j < V; j++) s[j] = s[j] + reinterpret_cast<const float *>(&v)[j];
             }
+    }
+    comb16v<V>(s, tot, sh, wave, lane);
+    const float fr = (float)R;
+#pragma unroll
+    for (int j = 0; j < V; j++) { mean[j] = tot[j] / fr; s[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        if (valid(i)) {
+#pragma unroll
+            for (int j = 0; j < V; j++) { const float d = x[i][j] - mean[j]; s[j] = __builtin_fmaf(d, d, s[j]); }
         }
+    if (NL > 0) {
+#pragma unroll
+        for (int i = NR; i < NR + NL; i++)
+            if (valid(i)) {
+                const vec v = hold[i - NR][tid];
+#pragma unroll
+                for (int j = 0; j < V; j++) { const float d = reinterpret_cast<const float *>(&v)[j] - mean[j]; s[j] = __builtin_fmaf(d, d, s[j]); }
+            }
+    }
+    comb16v<V>(s, tot, sh, wave, lane);
+#pragma unroll
+    for (int j = 0; j < V; j++) var[j] = tot[j] / fr;
+    if (tid < 16) {
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            if (out_mean) out_mean[(long long)g * SSLAM_C + ch0 + j] = mean[j];
+            if (out_var) out_var[(long long)g * SSLAM_C + ch0 + j] = var[j];
+        }
+    }
+    float al[V], bs[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        al[j] = (1.0f / sqrtf(var[j] + eps)) * gamma[ch0 + j];
+        bs[j] = beta[ch0 + j] - mean[j] * al[j];
+    }
+    float *dst = out_feat + (long long)g * R * SSLAM_C;                                      // uniform
+    unsigned *dst_bf = out_bf16 ? out_bf16 + (long long)g * R * (SSLAM_C / 2) : nullptr;     // one dword = two bf16
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto emit = [&](int i, const float (&xv)[V]) {
+        float y[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) y[j] = xv[j] * al[j] + bs[j];
+        *reinterpret_cast<vec *>(dst + (size_t)i * 16 * SSLAM_C + loff) = *reinterpret_cast<const vec *>(y);
+        if (dst_bf) {   // bf16 copy for the throughput-mode saliency CNN (selector_bf16.hip)
+            unsigned o[V / 2];
+#pragma unroll
+            for (int j = 0; j < V / 2; j++) {
+                const f32x2 pr = {y[2 * j], y[2 * j + 1]};
+                o[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+            }
+            unsigned *q = dst_bf + (size_t)i * 16 * (SSLAM_C / 2) + loff / 2;
+            if (V == 4) *reinterpret_cast<uint2 *>(q) = make_uint2(o[0], o[V / 2 - 1]);
+            else *q = o[0];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        if (valid(i)) emit(i, x[i]);
+    if (NL > 0) {
+#pragma unroll
+        for (int i = NR; i < NR + NL; i++)
+            if (valid(i)) {
+                const vec v = hold[i - NR][tid];
+                float xv[V];
+#pragma unroll
+                for (int j = 0; j < V; j++) xv[j] = reinterpret_cast<const float *>(&v)[j];
+                emit(i, xv);
+            }
+    }
 }
 
 }  // namespace
@@ -212,9 +303,19 @@ static int bn_launch(const float *tokens, int n_frames, int tokens_per_frame, in
          (uintptr_t)run_var | (uintptr_t)out_mean | (uintptr_t)out_var | (uintptr_t)out_bf16) & 15)
         return SSLAM_E_INVALID;
     if ((long long)group * (tokens_per_frame - n_prefix) > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
-    if (train && group == 1 && tokens_per_frame - n_prefix <= 16 * 49) {
-        hipLaunchKernelGGL(bn_tokens_reg_kernel<49>, dim3(n_frames, SSLAM_C / 64), dim3(256), 0, (hipStream_t)stream, tokens,
-                           tokens_per_frame, n_prefix, gamma, beta, eps, out_feat, out_mean, out_var, (uint2 *)out_bf16);
+    const int cells = tokens_per_frame - n_prefix;
+    if (train && group == 1 && cells <= 16 * 225 && sslam_knob(KNOB_BN_FORM, 0) != 1) {
+        // one HBM read instead of three: every lane keeps its rows on the chip between the sweeps (bn_tokens_reg_kernel)
+        hipStream_t st = (hipStream_t)stream;
+        if (cells <= 16 * 49)
+            hipLaunchKernelGGL((bn_tokens_reg_kernel<4, 49, 0, 2>), dim3(n_frames, SSLAM_C / 64), dim3(256), 0, st, tokens, tokens_per_frame,
+                               n_prefix, gamma, beta, eps, out_feat, out_mean, out_var, (unsigned *)out_bf16);
+        else if (cells <= 16 * 100)
+            hipLaunchKernelGGL((bn_tokens_reg_kernel<4, 100, 0, 1>), dim3(n_frames, SSLAM_C / 64), dim3(256), 0, st, tokens, tokens_per_frame,
+                               n_prefix, gamma, beta, eps, out_feat, out_mean, out_var, (unsigned *)out_bf16);
+        else
+            hipLaunchKernelGGL((bn_tokens_reg_kernel<2, 200, 25, 1>), dim3(n_frames, SSLAM_C / 32), dim3(256), 0, st, tokens, tokens_per_frame,
+                               n_prefix, gamma, beta, eps, out_feat, out_mean, out_var, (unsigned *)out_bf16);
         SSLAM_CHECK_LAUNCH();
         return SSLAM_OK;
     }

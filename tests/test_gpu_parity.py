@@ -67,9 +67,18 @@ def test_mfma_chain_is_fmaf_chain(T, hip):
 
 
 # --------------------------------------------------------------------------------------------------------- A2
-@pytest.mark.parametrize("grid,batch,group,train", [(28, 2, 1, True), (28, 2, 2, True), (28, 2, 1, False), (40, 1, 1, True),
-                                                    (60, 3, 3, True), (27, 3, 1, True), (7, 4, 1, True), (3, 2, 1, True)])
-def test_bn_tokens(T, hip, grid, batch, group, train):
+@pytest.mark.parametrize("sweeps", [False, True])
+@pytest.mark.parametrize("grid,batch,group,train", [(28, 2, 1, True), (28, 2, 2, True), (28, 2, 1, False), (40, 1, 1, True), (40, 3, 1, True),
+                                                    (60, 3, 3, True), (60, 2, 1, True), (50, 2, 1, True), (33, 2, 1, True), (27, 3, 1, True),
+                                                    (7, 4, 1, True), (3, 2, 1, True)])
+def test_bn_tokens(T, hip, grid, batch, group, train, sweeps, knob):
+    """Per-frame statistics (group 1) run register-resident - one HBM read - at every grid up to 60 x 60 (three forms: 4 or 2
+    channels per lane, the largest with part of the rows in LDS); `sweeps` forces the three-sweep kernel that groups > 1, eval
+    mode and larger grids use.  All bit-identical to the oracle."""
+    if sweeps:
+        if not (train and group == 1):
+            pytest.skip("already the three-sweep kernel")
+        knob("SSLAM_BN_FORM", 1)
     tok = synth.tokens(10 + grid, grid, batch)
     rng = np.random.Generator(np.random.PCG64(grid))
     gamma = (1 + 0.1 * rng.standard_normal(384)).astype(np.float32)
