@@ -110,7 +110,7 @@ class StreamingSequence:
         for s, bufs in self._pairs.items():
             if n > s:
                 res[s] = {k: v[:n - s] for k, v in bufs.items()}
-                res[s]["first"] = torch.arange(0, n - s, dtype=torch.int64, device=bufs["quality"].device)
+                res[s]["first"] = torch.arange(0, n - s, dtype=torch.int64, device=bufs["match_count"].device)
         return res
 
     # ---------------------------------------------------------------------------------------------- push

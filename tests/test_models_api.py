@@ -259,18 +259,55 @@ def test_streaming_scheduler_pair_bookkeeping():
         class cfg:
             spacing = 1
 
-        def extract(self, tokens, images=None):
-            return {"descriptors": tokens.clone(), "scores": tokens.clone()}
+        def alloc_extract(self, n, with_intensity):
+            return {"descriptors": torch.full((n,), -1.0), "scores": torch.full((n,), -1.0)}
 
-        def match(self, desc, scores, intensity=None, spacing=1):
+        def alloc_match(self, n_pairs):
+            return {"match_count": torch.full((n_pairs,), -1, dtype=torch.int32), "pair": torch.full((n_pairs, 2), -1.0)}
+
+        def extract(self, tokens, images=None, out=None, images_ready=None):
+            if out is None:
+                return {"descriptors": tokens.clone(), "scores": tokens.clone()}
+            out["descriptors"][:] = tokens
+            out["scores"][:] = tokens
+            return out
+
+        def match(self, desc, scores, intensity=None, spacing=1, out=None):
             n = desc.shape[0] - spacing
-            return {"match_count": torch.zeros(n, dtype=torch.int32), "pair": torch.stack([desc[:n], desc[spacing:]], 1)}
+            res = out if out is not None else self.alloc_match(n)
+            res["match_count"][:] = 0
+            res["pair"][:] = torch.stack([desc[:n], desc[spacing:]], 1)
+            return dict(res)
 
     n = 31
     frames = torch.arange(n, dtype=torch.float32)
     for chunk in (None, 1, 4, 13, 40):
-        res = StreamingSequence(_Pipe(), (1, 5, 10, 15, 20)).run(frames, None, chunk=chunk)
+        # a sequence of known length: sequence-sized buffers written in place (every pair exactly once, whatever the chunking)
+        seq = StreamingSequence(_Pipe(), (1, 5, 10, 15, 20))
+        res = seq.run(frames, None, chunk=chunk)
+        assert seq._ring is None and torch.equal(res["frames"]["descriptors"], frames)
+        # an unbounded stream: the ring of the last max(spacings) frames
+        ring = StreamingSequence(_Pipe(), (1, 5, 10, 15, 20))
+        step = n if chunk is None else chunk
+        outs = [ring.push(frames[a:a + step]) for a in range(0, n, step)]
+        assert ring._ring["descriptors"].shape[0] == min(20, n)
         for s in (1, 5, 10, 15, 20):
             want = torch.stack([frames[:n - s], frames[s:]], 1)
             assert torch.equal(res[s]["pair"], want), (chunk, s)
             assert res[s]["first"].tolist() == list(range(n - s))
+            assert int(res[s]["match_count"].min()) == 0                        # every row was written
+            assert torch.equal(torch.cat([o[s]["pair"] for o in outs if s in o]), want), (chunk, s)
+    with pytest.raises(ValueError):
+        seq = StreamingSequence(_Pipe(), (1,))
+        seq.reset(capacity=3)
+        seq.push(frames[:4])
+
+
+def test_chunk_bounds_and_feeder_arguments():
+    from sslam_amd.harness import FrameFeeder, chunk_bounds
+    assert chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert chunk_bounds(10, 4, 2) == [(0, 2), (2, 6), (6, 10)]
+    assert chunk_bounds(3, 8, 16) == [(0, 3)]
+    assert chunk_bounds(0, 8) == []
+    with pytest.raises(ValueError):
+        FrameFeeder(4, 2, 2, "cpu", [(0, 4)])                                   # neither fill nor pinned_source
