@@ -288,16 +288,19 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
     if (ksize_h <= 0 || ksize_v <= 0 || ksize_h > SSLAM_MAX_TAPS || ksize_v > SSLAM_MAX_TAPS) return SSLAM_E_INVALID;
     // input rows one output tile can need: TY output rows span TY*scale input rows plus the filter support
     if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
-    const bool aligned = !((uintptr_t)img & 3);
     // the fast kernel prefers 32-row tiles (less vertical-halo re-filtering) when their input rows fit its LDS buffer
     const bool tall = (32LL * h + size - 1) / size + ksize_v + 2 <= 64;
     // launch groups: grid.z <= 65535 and, for the fast kernel, all byte offsets of a group inside one 32-bit descriptor
     const long long fbytes = (long long)h * w * 3;
     if (fbytes > 0x7fffffffLL) return SSLAM_E_UNSUPPORTED;
-    const int per_group = (int)std::min<long long>(65535, std::max<long long>(1, 0xfffffff0LL / fbytes));
+    int per_group = (int)std::min<long long>(65535, std::max<long long>(1, 0xfffffff0LL / fbytes));
+    // the fast kernel realigns its loads against a dword-aligned group base: with odd frame sizes (h * w * 3 not a multiple
+    // of 4) keep every group's base aligned by cutting groups at multiples of 4 frames
+    if ((fbytes & 3) && per_group >= 4) per_group &= ~3;
     for (int n0 = 0; n0 < n; n0 += per_group) {
         const int ng = std::min(per_group, n - n0);
         const uint8_t *gi = img + (long long)n0 * fbytes;
+        const bool aligned = !((uintptr_t)gi & 3);              // per GROUP: the generic kernel takes an unaligned one
         float *go = out_chw + (long long)n0 * 3 * size * size;
         const unsigned gbytes = (unsigned)(ng * fbytes);
         const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, ng);

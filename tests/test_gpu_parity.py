@@ -230,6 +230,13 @@ def test_preprocess_and_intensity(T, hip, h, w, size):
     for i in range(2):
         _, chw = ora.resize_rgb(imgs[i], size)
         assert_bits(out[i], chw, "preprocess")
+    # a frame batch whose BASE is not dword-aligned (a view at an odd byte offset): the generic kernel serves it, same bits
+    raw = T.empty(imgs.size + 3, dtype=T.uint8, device="cuda")
+    for off in (1, 2):
+        view = raw[off:off + imgs.size].view(imgs.shape)
+        view.copy_(dev(T, imgs))
+        assert view.data_ptr() % 4 == off
+        assert_bits(hip.preprocess_u8(view, size, th, tv).cpu().numpy(), out, "preprocess, unaligned base")
     th = tuple(dev(T, a) if isinstance(a, np.ndarray) else a for a in hip.resample_table(w, size, True))
     tv = tuple(dev(T, a) if isinstance(a, np.ndarray) else a for a in hip.resample_table(h, size, True))
     rng = np.random.Generator(np.random.PCG64(size))

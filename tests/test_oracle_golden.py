@@ -356,3 +356,22 @@ def test_match_wide_vs_reference():
         assert np.abs(q - g[f"p{s}_quality"]).max(initial=0.0) < 1e-6, s
         total += len(mt)
     assert total > 500
+
+
+def test_bf16_mode_checker_tracks_the_exact_oracle():
+    """oracle/ora_bf16.py (the definition the bf16 throughput mode's kernels are checked against: the reference's algorithm
+    with bf16-rounded GEMM operands) stays within the mode's drift bounds of the reference's own fp32 outputs (goldens made
+    by running the reference's modules) - it is the same algorithm, only the operand rounding differs."""
+    from oracle.ora_bf16 import bf16_round, refine_bf16_ref, saliency_bf16_ref
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.0e-39, 65504.0], np.float32)         # ties to even, denormal, large
+    assert bf16_round(x).tolist() == [1.0, 1.0, 1.015625, bf16_round(np.float32(-3.0e-39)).item(), 65536.0]
+    g = gold("selector")
+    feat = ora.bn_tokens(synth.tokens(1, 28))[0].reshape(1, 28, 28, 384)
+    sal = saliency_bf16_ref(feat, synth.selector_state(0))[0]
+    assert np.abs(sal - g["g28_saliency"]).max() < 3e-2
+    assert np.abs(sal - g["g28_saliency"]).mean() < 3e-3
+    gd = gold("gather_refine")
+    xk = ora.gather(feat, g["g28_kp"][None])
+    desc = refine_bf16_ref(xk.reshape(-1, 384), synth.refiner_state(0))
+    cos = (desc * gd["g28_desc"]).sum(-1)
+    assert cos.min() > 0.999 and np.abs(np.linalg.norm(desc, axis=-1) - 1).max() < 1e-6
