@@ -84,6 +84,14 @@ int sslam_resample_table_host(int in_size, int out_size, int filter, int32_t *bo
 int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
                         const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
                         int ksize_v, float *out_chw, void *stream);
+/* The same arithmetic, written as the patch-embedding operand of sslam_vit_forward_patches instead of the planar image:
+ * out (n, (size/16)^2, 768) bf16, row = patch (py, px), k = c*256 + ky*16 + kx - the normalised fp32 value of
+ * sslam_preprocess_u8 rounded to bf16 (round-to-nearest-even) once; size % 16 == 0.  SSLAM_E_UNSUPPORTED for resampling
+ * ratios the tiled kernel does not cover (more than 7 horizontal taps, or an image base that is not dword-aligned): take
+ * sslam_preprocess_u8 + sslam_vit_forward then. */
+int sslam_preprocess_u8_patches(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                                const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                                int ksize_v, void *out_patches_bf16, void *stream);
 
 /* ---- A2: token drop + BatchNorm1d over tokens.  Replaces DinoBackbone.forward after the ViT call,
  * dino_backbone.py:91-106.  tokens (n_frames, tokens_per_frame, 384); statistics over `group` consecutive frames
@@ -244,6 +252,10 @@ int sslam_vit_pack_mlp_host(const float *w_up, const float *w_down, const float 
 long long sslam_vit_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
                       void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
+/* the same forward from the bf16 patch rows of sslam_preprocess_u8_patches (n, (size/16)^2, 768): no fp32 image, no
+ * im2patch pass; bit-identical tokens (the patch embedding rounds the image to bf16 either way) */
+int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
+                              void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 //  - the uint8 intermediate row is kept packed (R | G<<8 | B<<16) so the vertical pass reads one dword per tap;
 //  - the vertical coefficients of an output row are wave-uniform (a wave owns whole rows): scalar loads.
 //  - TAPS (3, 5 or 7) is the compile-time tap count: 640 -> 448 bilinear needs 5, so two of seven tap slots would be zeros.
-template <int TAPS, int TYT, int MAXRT>
+//  - PATCH = true: the output is not the planar fp32 image but the ViT's patch-embedding operand - bf16 rows of 768 per
+//    16 x 16 patch, k = c * 256 + ky * 16 + kx (what im2patch_kernel of vit.hip made from the fp32 image): the same
+//    normalised value rounded to bf16 once.  Half the bytes written, and the fp32 image + the im2patch pass disappear.
+template <int TAPS, int TYT, int MAXRT, bool PATCH = false>
 __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__restrict__ img, unsigned total_bytes, int h, int w,
                                                                int size, const int *__restrict__ bh, const int *__restrict__ ch,
                                                                int ksh, const int *__restrict__ bv, const int *__restrict__ cv,
@@ -182,10 +185,19 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const uint8_t *__r
                     s1 += __mul24((int)((p >> 8) & 255), kk);
                     s2 += __mul24((int)((p >> 16) & 255), kk);
                 }
-                float *o = out + (long long)f * 3 * plane + (long long)oy * size + (x0 + xx);
-                o[0] = lut[0][clip8(s0)];
-                o[plane] = lut[1][clip8(s1)];
-                o[2 * plane] = lut[2][clip8(s2)];
+                if constexpr (PATCH) {
+                    const int G = size >> 4, ox_ = x0 + xx;
+                    __bf16 *o = reinterpret_cast<__bf16 *>(out) +
+                                (((long long)f * G + (oy >> 4)) * G + (ox_ >> 4)) * 768 + (oy & 15) * 16 + (ox_ & 15);
+                    o[0] = (__bf16)lut[0][clip8(s0)];
+                    o[256] = (__bf16)lut[1][clip8(s1)];
+                    o[512] = (__bf16)lut[2][clip8(s2)];
+                } else {
+                    float *o = out + (long long)f * 3 * plane + (long long)oy * size + (x0 + xx);
+                    o[0] = lut[0][clip8(s0)];
+                    o[plane] = lut[1][clip8(s1)];
+                    o[2 * plane] = lut[2][clip8(s2)];
+                }
             }
         }
     }
@@ -280,12 +292,13 @@ extern "C" int sslam_resample_table_host(int in_size, int out_size, int filter, 
     return ksize;
 }
 
-extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
-                                   const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
-                                   int ksize_v, float *out_chw, void *stream) {
-    if (!img || !bounds_h || !coefs_h || !bounds_v || !coefs_v || !out_chw || n <= 0 || h <= 0 || w <= 0 || size <= 0)
+template <bool PATCH>
+static int preprocess_launch(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h, const int32_t *coefs_h,
+                             int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v, int ksize_v, void *out_v, void *stream) {
+    if (!img || !bounds_h || !coefs_h || !bounds_v || !coefs_v || !out_v || n <= 0 || h <= 0 || w <= 0 || size <= 0)
         return SSLAM_E_INVALID;
     if (ksize_h <= 0 || ksize_v <= 0 || ksize_h > SSLAM_MAX_TAPS || ksize_v > SSLAM_MAX_TAPS) return SSLAM_E_INVALID;
+    if (PATCH && (size % 16 || ((uintptr_t)out_v & 1))) return SSLAM_E_INVALID;
     // input rows one output tile can need: TY output rows span TY*scale input rows plus the filter support
     if ((long long)(TY * (long long)h + size - 1) / size + ksize_v + 2 > MAXR) return SSLAM_E_UNSUPPORTED;
     // the fast kernel prefers 32-row tiles (less vertical-halo re-filtering) when their input rows fit its LDS buffer
@@ -301,17 +314,19 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
         const int ng = std::min(per_group, n - n0);
         const uint8_t *gi = img + (long long)n0 * fbytes;
         const bool aligned = !((uintptr_t)gi & 3);              // per GROUP: the generic kernel takes an unaligned one
-        float *go = out_chw + (long long)n0 * 3 * size * size;
+        // group output: planar fp32 (3 * size^2 floats per frame) or bf16 patch rows (3 * size^2 bf16 per frame)
+        float *go = PATCH ? reinterpret_cast<float *>(reinterpret_cast<__bf16 *>(out_v) + (long long)n0 * 3 * size * size)
+                          : reinterpret_cast<float *>(out_v) + (long long)n0 * 3 * size * size;
         const unsigned gbytes = (unsigned)(ng * fbytes);
         const dim3 grid((size + TX - 1) / TX, (size + TY - 1) / TY, ng);
         const dim3 grid32((size + TX - 1) / TX, (size + 31) / 32, ng);
 #define FAST(T)                                                                                                        \
     {                                                                                                                  \
         if (tall)                                                                                                      \
-            hipLaunchKernelGGL((preprocess_fast_kernel<T, 32, 64>), grid32, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, 32, 64, PATCH>), grid32, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
                                size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, go);                      \
         else                                                                                                           \
-            hipLaunchKernelGGL((preprocess_fast_kernel<T, TY, MAXR>), grid, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
+            hipLaunchKernelGGL((preprocess_fast_kernel<T, TY, MAXR, PATCH>), grid, dim3(256), 0, (hipStream_t)stream, gi, gbytes, h, w, \
                                size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, go);                      \
     }
         if (ksize_h <= 3 && aligned)
@@ -320,6 +335,8 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
             FAST(5)
         else if (ksize_h <= 7 && aligned)
             FAST(7)
+        else if (PATCH)
+            return SSLAM_E_UNSUPPORTED;          // patch rows come from the fast kernel only (callers take the fp32 entry then)
         else
             hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, gi, h, w, size, bounds_h, coefs_h,
                                ksize_h, bounds_v, coefs_v, ksize_v, go);
@@ -327,6 +344,18 @@ extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int 
     }
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
+}
+
+extern "C" int sslam_preprocess_u8(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                                   const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                                   int ksize_v, float *out_chw, void *stream) {
+    return preprocess_launch<false>(img, n, h, w, size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_chw, stream);
+}
+
+extern "C" int sslam_preprocess_u8_patches(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,
+                                           const int32_t *coefs_h, int ksize_h, const int32_t *bounds_v, const int32_t *coefs_v,
+                                           int ksize_v, void *out_patches_bf16, void *stream) {
+    return preprocess_launch<true>(img, n, h, w, size, bounds_h, coefs_h, ksize_h, bounds_v, coefs_v, ksize_v, out_patches_bf16, stream);
 }
 
 extern "C" int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, const int32_t *bounds_h,

@@ -1087,11 +1087,12 @@ extern "C" long long sslam_vit_workspace_bytes(int n_frames, int size) {
     return (long long)b;
 }
 
-extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *w, void *workspace,
-                                 long long workspace_bytes, float *tokens_out, void *stream) {
-    if (!images_chw || !w || !workspace || !tokens_out || n_frames <= 0 || size <= 0 || size % VPATCH) return SSLAM_E_INVALID;
+// images_chw (fp32 planar; patches == nullptr) or patches (bf16 rows of 768 per patch, from sslam_preprocess_u8_patches)
+static int vit_forward_impl(const float *images_chw, const bf16 *patches, int n_frames, int size, const sslam_vit_weights_t *w,
+                            void *workspace, long long workspace_bytes, float *tokens_out, void *stream) {
+    if ((!images_chw && !patches) || !w || !workspace || !tokens_out || n_frames <= 0 || size <= 0 || size % VPATCH) return SSLAM_E_INVALID;
     if (workspace_bytes < sslam_vit_workspace_bytes(n_frames, size)) return SSLAM_E_INVALID;
-    if (((uintptr_t)images_chw | (uintptr_t)workspace | (uintptr_t)tokens_out) & 15) return SSLAM_E_INVALID;
+    if (((uintptr_t)images_chw | (uintptr_t)patches | (uintptr_t)workspace | (uintptr_t)tokens_out) & 15) return SSLAM_E_INVALID;
     const int G = size / VPATCH, cells = G * G, T = cells + VPREFIX;
     const long long rows = (long long)n_frames * T, prow = (long long)n_frames * cells;
     if (rows * VMLP > 0x7fffffffLL * 64) return SSLAM_E_UNSUPPORTED;
@@ -1108,10 +1109,12 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
 
     // patch embedding + prefix tokens
     {
-        const long long items = prow * 96;
-        hipLaunchKernelGGL(im2patch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, images_chw, size, items, hbuf);
-        g_sslam_launches++;
-        launch_rt<2, 1>(ProBf16{hbuf, 768}, (const bf16 *)w->patch_w, prow, VD, EpiPatch{w->patch_b, x, stats, cells, T}, st);
+        if (!patches) {
+            const long long items = prow * 96;
+            hipLaunchKernelGGL(im2patch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, images_chw, size, items, hbuf);
+            g_sslam_launches++;
+        }
+        launch_rt<2, 1>(ProBf16{patches ? patches : hbuf, 768}, (const bf16 *)w->patch_w, prow, VD, EpiPatch{w->patch_b, x, stats, cells, T}, st);
         g_sslam_launches++;
         hipLaunchKernelGGL(prefix_rows_kernel, dim3(n_frames * VPREFIX), dim3(64), 0, st, w->prefix, T, x, stats);
         g_sslam_launches++;
@@ -1156,4 +1159,16 @@ extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size
     hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, (void *)tokens_out);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
+}
+
+extern "C" int sslam_vit_forward(const float *images_chw, int n_frames, int size, const sslam_vit_weights_t *w, void *workspace,
+                                 long long workspace_bytes, float *tokens_out, void *stream) {
+    if (!images_chw) return SSLAM_E_INVALID;
+    return vit_forward_impl(images_chw, nullptr, n_frames, size, w, workspace, workspace_bytes, tokens_out, stream);
+}
+
+extern "C" int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, const sslam_vit_weights_t *w, void *workspace,
+                                         long long workspace_bytes, float *tokens_out, void *stream) {
+    if (!patches_bf16) return SSLAM_E_INVALID;
+    return vit_forward_impl(nullptr, (const bf16 *)patches_bf16, n_frames, size, w, workspace, workspace_bytes, tokens_out, stream);
 }

@@ -64,6 +64,7 @@ EXPORTS = [
     "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
     "sslam_workspace_bytes", "sslam_selector_saliency_workspace_bytes", "sslam_sim_argmax_workspace_bytes",
     "sslam_selector_saliency_ws", "sslam_sim_argmax_ws", "sslam_test_set_knob",
+    "sslam_preprocess_u8_patches", "sslam_vit_forward_patches",
 ]
 
 
@@ -82,6 +83,7 @@ def lib():
         L.sslam_pack_linear_host.argtypes = [p, i, i, p]
         L.sslam_resample_table_host.argtypes = [i, i, i, p, p, i]
         L.sslam_preprocess_u8.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, p]
+        L.sslam_preprocess_u8_patches.argtypes = [p, i, i, i, i, p, p, i, p, p, i, p, p]
         L.sslam_bn_tokens.argtypes = [p, i, i, i, i, p, p, p, p, i, f, p, p, p, p]
         L.sslam_selector_saliency.argtypes = [p, i, i, p, p, p, p, i, p, p]
         L.sslam_selector_saliency_ws.argtypes = [p, i, i, p, p, p, p, i, p, p, ll, p]
@@ -113,6 +115,7 @@ def lib():
         L.sslam_vit_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
+        L.sslam_vit_forward_patches.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
         _lib = L
     return _lib
 
@@ -254,6 +257,24 @@ def preprocess_u8(img, size, tab_h, tab_v, out=None):
     (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
     _run("preprocess_u8", lib().sslam_preprocess_u8, (img, bh, ch, bv, cv, out,),
          _dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(out))
+    return out
+
+
+def preprocess_u8_patches(img, size, tab_h, tab_v, out=None):
+    """A0 written as the ViT's patch-embedding operand: (n, (size/16)^2, 768) bf16 (include/sslam_hip.h).  Returns None where the
+    tiled kernel does not cover the resampling ratio (callers then take preprocess_u8 + vit_forward)."""
+    n, h, w, _ = img.shape
+    assert img.dtype == torch.uint8 and size % 16 == 0
+    if out is None:
+        out = torch.empty((n, (size // 16) ** 2, 768), dtype=torch.bfloat16, device=img.device)
+    (bh, ch, kh), (bv, cv, kv) = tab_h, tab_v
+    dev = common_device(img, bh, ch, bv, cv, out)
+    with torch.cuda.device(dev):
+        rc = lib().sslam_preprocess_u8_patches(_dp(img), n, h, w, size, _dp(bh), _dp(ch), kh, _dp(bv), _dp(cv), kv, _dp(out),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc == E_UNSUPPORTED:
+        return None
+    _check(rc, "preprocess_u8_patches")
     return out
 
 
@@ -459,6 +480,17 @@ def vit_workspace_bytes(n_frames: int, size: int) -> int:
     if b < 0:
         _check(b, "vit_workspace_bytes")
     return b
+
+
+def vit_forward_patches(patches, size: int, weights: VitWeights, workspace, out=None):
+    """patches (n, (size/16)^2, 768) bf16 from preprocess_u8_patches -> tokens (n, 5 + (size/16)^2, 384) fp32."""
+    n = patches.shape[0]
+    t = 5 + (size // 16) ** 2
+    if out is None:
+        out = torch.empty((n, t, C_FEAT), dtype=torch.float32, device=patches.device)
+    _run("vit_forward_patches", lib().sslam_vit_forward_patches, (patches, workspace, out,),
+         _dp(patches), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(), _dp(out))
+    return out
 
 
 def vit_forward(images_chw, weights: VitWeights, workspace, out=None):

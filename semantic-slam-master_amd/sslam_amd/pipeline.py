@@ -215,13 +215,27 @@ class SequencePipeline:
         if vit_chunk is None:
             vit_chunk = self.vit_hip.chunk_frames(self.cfg.input_size)
         out = torch.empty((images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT), dtype=torch.float32, device=self.device)
-        # A0 runs over 16 launch groups at a time (bounds the fp32 ViT input: 3.1 GB at 448 x 448); the ViT then alternates
-        # those groups between its two streams
+        # A0 runs over 16 launch groups at a time (bounds the ViT input: 1.6 GB of bf16 patch rows at 448 x 448); the ViT then
+        # alternates those groups between its two streams.  A0 writes the patch-embedding operand directly (bf16 rows of 768 per
+        # patch): no fp32 image, no im2patch pass; resampling ratios its tiled kernel does not cover take the fp32 image.
         span = 16 * vit_chunk
-        for a in range(0, images_u8.shape[0], span):
-            b = min(a + span, images_u8.shape[0])
-            self.vit_hip.forward_features(self.preprocess(images_u8[a:b]), out=out[a:b], chunk=vit_chunk)
+        size = self.cfg.input_size
+        n, h, w, _ = images_u8.shape
+        th, tv = self.tables.get(h, w, size, False)
+        for a in range(0, n, span):
+            b = min(a + span, n)
+            patches = lib.preprocess_u8_patches(images_u8[a:b], size, th, tv)
+            if patches is not None:
+                self.vit_hip.forward_features(None, out=out[a:b], chunk=vit_chunk, patches=patches, size=size)
+            else:
+                self.vit_hip.forward_features(self.preprocess(images_u8[a:b]), out=out[a:b], chunk=vit_chunk)
         return out
+
+    def preprocess_patches(self, images_u8: torch.Tensor):
+        """A0 as the ViT consumes it: (N, H, W, 3) uint8 -> (N, G*G, 768) bf16 patch rows (None: ratio not covered, see lib)."""
+        n, h, w, _ = images_u8.shape
+        th, tv = self.tables.get(h, w, self.cfg.input_size, False)
+        return lib.preprocess_u8_patches(images_u8, self.cfg.input_size, th, tv)
 
     def features(self, tokens: torch.Tensor, bf16_copy: bool = False):
         """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features

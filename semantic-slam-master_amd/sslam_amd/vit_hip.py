@@ -65,10 +65,19 @@ class HipViT:
         64 frames = a partial round: 13.3 k).  Several groups alternate between two streams (forward_features)."""
         return max(1, (506 * 128) // (5 + (size // 16) ** 2))
 
-    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
-        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group."""
-        n, _, s, s2 = images.shape
-        assert s == s2 and s % 16 == 0 and images.is_cuda
+    def forward_features(self, images: torch.Tensor | None, out: torch.Tensor | None = None, chunk: int | None = None,
+                         patches: torch.Tensor | None = None, size: int | None = None) -> torch.Tensor:
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), `chunk` frames per launch group.
+        patches (with size = S): the bf16 patch rows of lib.preprocess_u8_patches (B, (S/16)^2, 768) instead of the image -
+        no fp32 image, no im2patch pass, the same tokens bit for bit."""
+        if patches is not None:
+            n, s = patches.shape[0], int(size)
+            assert patches.is_cuda and patches.dtype == torch.bfloat16 and patches.shape[1:] == ((s // 16) ** 2, 768)
+            dev_of = patches
+        else:
+            n, _, s, s2 = images.shape
+            assert s == s2 and s % 16 == 0 and images.is_cuda
+            dev_of = images
         g = s // 16
         if g not in self._rope:
             cos, sin = self.vit.rope_tables(g, g, self.device)
@@ -76,16 +85,23 @@ class HipViT:
         self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
         step = chunk or self.chunk_frames(s)
         need = lib.vit_workspace_bytes(min(n, step), s)
-        x = images.detach().float().contiguous()
+        x = patches.contiguous() if patches is not None else images.detach().float().contiguous()
         if out is None:
-            out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
+            out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=dev_of.device)
+
+        def launch(a, ws):
+            if patches is not None:
+                lib.vit_forward_patches(x[a:a + step], s, self.w, ws, out=out[a:a + step])
+            else:
+                lib.vit_forward(x[a:a + step], self.w, ws, out=out[a:a + step])
+
         starts = list(range(0, n, step))
         if len(starts) >= 2 and self.n_streams >= 2:
             # Launch groups alternate between two side streams: every launch has a ramp and an uneven tail (mean workgroup lifetime x
             # workgroups / slots explains only 60 of the QKV launch's 86 us), and the other group's kernels fill them
             # (tools/vit_streams.py: +3-5 % at 82 frames per group; a third stream adds nothing).  The caller's stream semantics are
             # kept: the side streams start after the current stream's work and the current stream waits for them.
-            dev = images.device
+            dev = dev_of.device
             cur = torch.cuda.current_stream(dev)
             if self._side is None:
                 self._side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
@@ -98,7 +114,7 @@ class HipViT:
                 if i < 2:
                     st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    lib.vit_forward(x[a:a + step], self.w, self._side_ws[i & 1], out=out[a:a + step])
+                    launch(a, self._side_ws[i & 1])
             for st in self._side:
                 x.record_stream(st)
                 out.record_stream(st)
@@ -107,5 +123,5 @@ class HipViT:
         if self._side_ws[0] is None or self._side_ws[0].numel() < need:
             self._side_ws[0] = torch.empty(need, dtype=torch.uint8, device=self.device)
         for a in starts:
-            lib.vit_forward(x[a:a + step], self.w, self._side_ws[0], out=out[a:a + step])
+            launch(a, self._side_ws[0])
         return out

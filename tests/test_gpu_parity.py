@@ -230,6 +230,17 @@ def test_preprocess_and_intensity(T, hip, h, w, size):
     for i in range(2):
         _, chw = ora.resize_rgb(imgs[i], size)
         assert_bits(out[i], chw, "preprocess")
+    # the same arithmetic written as the ViT's patch-embedding operand (bf16 rows of 768 per 16 x 16 patch, k = c*256 + ky*16 + kx)
+    if size % 16 == 0:
+        from oracle.ora_bf16 import bf16_round
+        pt = hip.preprocess_u8_patches(dev(T, imgs), size, th, tv)
+        g16 = size // 16
+        want = out.reshape(2, 3, g16, 16, g16, 16).transpose(0, 2, 4, 1, 3, 5).reshape(2, g16 * g16, 768)
+        if th[2] > 7:
+            assert pt is None          # more than 7 horizontal taps: the tiled kernel does not cover the ratio (callers take the fp32 image)
+        else:
+            assert pt is not None and pt.shape == (2, g16 * g16, 768) and pt.dtype == T.bfloat16
+            assert_bits(pt.float().cpu().numpy(), bf16_round(want), "patch rows")
     # a frame batch whose BASE is not dword-aligned (a view at an odd byte offset): the generic kernel serves it, same bits
     raw = T.empty(imgs.size + 3, dtype=T.uint8, device="cuda")
     for off in (1, 2):

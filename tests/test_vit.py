@@ -91,6 +91,25 @@ def test_hip_vit_layernorm_with_dc_offset_and_outlier_channels(frames):
 
 
 @pytest.mark.gpu
+def test_hip_vit_from_patch_rows_equals_from_image():
+    """uint8 frames -> A0 as bf16 patch rows -> sslam_vit_forward_patches gives the tokens of A0 as fp32 image ->
+    sslam_vit_forward bit for bit (the patch embedding rounds the image to bf16 either way); no im2patch launch."""
+    import synth
+    from sslam_amd import lib
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    _, mine = _hf_pair(1)
+    pv = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda", vit=mine.cuda())
+    imgs = torch.from_numpy(synth.image_sequence(5)).cuda()
+    with torch.no_grad():
+        want = pv.vit_hip.forward_features(pv.preprocess(imgs)).clone()
+        n0 = lib.launch_count()
+        got = pv.tokens_from_images(imgs)
+    assert torch.equal(got, want)
+    pt = pv.preprocess_patches(imgs)
+    assert pt is not None and pt.shape == (5, 784, 768)
+
+
+@pytest.mark.gpu
 def test_hip_vit_launch_groups_on_two_streams_equal_one_group():
     """forward_features cuts the batch into launch groups and alternates them between two side streams; the result is the
     same bits as one group (the kernels are deterministic and a frame's tokens do not depend on its group), and it is visible
