@@ -479,9 +479,9 @@ def main():
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (FETCH_SIZE / WRITE_SIZE with
         # the gfx950 corrections of MI355X_MICROARCH.md, tools/pmc_summary.py); the committed summary is keyed by workload
         traffic = traffic_src = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+        pmc = cands[-1] if cands else ""
         if os.path.exists(pmc) and args.workload == "fr1_desk_613" and not args.frames:
             try:
                 k = sorted(((name, v) for name, v in json.load(open(pmc)).items() if name.startswith("selector_saliency")),

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Regenerates the profile artefacts of a round on the GPU box (run from the repo root):  bash tools/profile_round.sh r02
+# Regenerates the profile artefacts of a round on the GPU box (run from the repo root):  bash tools/profile_round.sh r03
 # Writes gpurun_out/<tag>_*: copy the ones to be judged into profiles/ afterwards.  Raw traces stay in /tmp on the box.
 # rocprofv3 is always given the program itself after `--`; --pmc passes carry only --kernel-trace (no other trace domain).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -14,18 +14,22 @@ BENCH="$ROOT/bench.py --steps 5 --warmup 2"
 VIT="$ROOT/tools/bench_vit.py 448 82"
 
 echo "[1/7] bench line"; python $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-echo "[2/7] kernel stats of the same command"
-rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats -d /tmp/ks -o x --output-format csv -- python $BENCH --no-cpu-baseline --no-vit > /dev/null 2>&1
+echo "[2/7] kernel stats of the same command, main leg only (every call of a kernel is then the same shape)"
+MAIN="--no-cpu-baseline --no-vit --no-bf16 --no-upload --no-directory"
+rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats -d /tmp/ks -o x --output-format csv -- python $BENCH $MAIN > $OUT/${TAG}_bench_profiled.json 2>/dev/null
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+# warm-only: the 2 warm-up steps' launches dropped, so that flop / AverageNs / peak from this file == roofline.frac of the line
+python $ROOT/tools/kstats_warm.py /tmp/ks $OUT/${TAG}_kernel_stats_warm.csv 2 > /dev/null
 echo "[3/7] HBM traffic + stall counters (separate --pmc passes)"
 rm -rf /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4
 P="--kernel-trace --kernel-include-regex $RX --output-format csv -o x"
-rocprofv3 --pmc FETCH_SIZE $P -d /tmp/pm1 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE $P -d /tmp/pm2 -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+PB="--steps 2 --warmup 1 --no-cpu-baseline --no-vit --no-upload --no-directory"
+rocprofv3 --pmc FETCH_SIZE $P -d /tmp/pm1 -- python $BENCH $PB > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE $P -d /tmp/pm2 -- python $BENCH $PB > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA $P -d /tmp/pm3 \
-  -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+  -- python $BENCH $PB > /dev/null 2>&1
 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES $P -d /tmp/pm4 \
-  -- python $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-vit > /dev/null 2>&1
+  -- python $BENCH $PB > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json /tmp/pm1 /tmp/pm2 /tmp/pm3 /tmp/pm4 > /dev/null
 echo "[4/7] ViT alone: bench, kernel stats, counters of the HEAD kernels"
 python $VIT > $OUT/${TAG}_vit_bench.txt
@@ -48,4 +52,11 @@ echo "[7/7] round quantisation of the conv / descriptor MLP launches, two-stream
 python $ROOT/tools/conv_rounds.py > $OUT/${TAG}_rounds.txt 2>/dev/null
 python $ROOT/tools/refine_rounds.py >> $OUT/${TAG}_rounds.txt 2>/dev/null
 python $ROOT/tools/vit_streams.py 82 8 >> $OUT/${TAG}_rounds.txt 2>/dev/null
+echo "[8] round-3 additions: A2 at the three grids, host -> device feed (sweep + event timeline), other workloads"
+python $ROOT/tools/bn_bench.py > $OUT/${TAG}_bn_grids.txt 2>/dev/null
+python $ROOT/tools/upload_sweep.py > $OUT/${TAG}_upload_sweep.txt 2>/dev/null
+python $ROOT/tools/upload_timeline.py 307 > $OUT/${TAG}_upload_timeline.txt 2>/dev/null
+for wl in fr1_xyz_50 fr2_desk_1024kp synthetic_2048kp; do
+  python $ROOT/bench.py --steps 5 --warmup 2 --workload $wl --no-cpu-baseline --no-vit --no-directory > $OUT/${TAG}_bench_$wl.json 2>/dev/null
+done
 echo done
