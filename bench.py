@@ -142,11 +142,12 @@ def path_roofline(fps, grid, K, hidden, h, w):
             "compulsory_bytes_per_frame": bytes_io, "hbm_tb_s": round(fps * bytes_io / 1e12, 3), "frac_of_hbm_8tb_s": round(fps * bytes_io / 8e12, 4)}
 
 
-def launch_plan(gpus: int, env: dict, device_count: int):
+def launch_plan(gpus: int, env: dict, device_count: int, shared_gpu: bool = False):
     """What `bench.py --gpus N` does, decided BEFORE anything touches a GPU.  Returns (action, message):
       "run"   - this process is one rank (WORLD_SIZE == N, the torch.distributed.run contract), or N == 1;
       "spawn" - N > 1 and no WORLD_SIZE: start N fresh rank processes with torch.distributed.run and pass rank 0's line through;
-      "error" - WORLD_SIZE != N, or fewer than N GPUs visible: exit non-zero instead of reporting a smaller job as N GPUs."""
+      "error" - WORLD_SIZE != N, or fewer than N GPUs visible: exit non-zero instead of reporting a smaller job as N GPUs.
+    shared_gpu (--rehearse-shared-gpu): N ranks may share fewer GPUs - a functional rehearsal over gloo that reports no value."""
     if gpus < 1:
         return "error", f"--gpus {gpus}: need at least one GPU"
     ws = env.get("WORLD_SIZE")
@@ -156,7 +157,7 @@ def launch_plan(gpus: int, env: dict, device_count: int):
         return "run", ""
     if gpus == 1:
         return "run", ""
-    if device_count < gpus:
+    if device_count < gpus and not (shared_gpu and device_count >= 1):
         return "error", f"--gpus {gpus} but only {device_count} GPU(s) visible on this node: refusing to report a smaller job as {gpus} GPUs"
     return "spawn", ""
 
@@ -191,10 +192,14 @@ def main():
                     "absent or not given: a synthetic directory of the workload's first frames is written to a temp dir")
     ap.add_argument("--tum-frames", type=int, default=128, help="frames of the directory leg (synthetic directory size / max_frames)")
     ap.add_argument("--no-directory", action="store_true", help="skip the directory -> matches leg")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="functional rehearsal of the N-rank path on fewer than N GPUs: ranks share the visible GPU(s), torch.distributed "
+                         "runs on gloo with device buffers staged through host memory, rank 0 checks sharded == single-process; "
+                         "prints a line with value null (NOT a measurement)")
     args = ap.parse_args()
 
     # nothing above this line and nothing in launch_plan touches a GPU (torch.cuda.device_count() only counts devices)
-    action, msg = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    action, msg = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), args.rehearse_shared_gpu)
     if action == "error":
         print(f"bench.py: {msg}", file=sys.stderr)
         sys.exit(2)
@@ -204,10 +209,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    rehearsal = bool(args.rehearse_shared_gpu and world > 1)
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")           # RCCL refuses two ranks on one GPU: the rehearsal stages through host memory
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks", file=sys.stderr)
             sys.exit(2)
@@ -289,7 +300,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -521,6 +532,21 @@ def main():
                            "shows 2 neighbour swaps in the keypoint ORDER (same keypoint set, saliencies < 1e-6 apart - the "
                            "summation-order noise of a 3456-term fp32 dot product), so for this workload index parity with the "
                            "reference holds as a set (tests/test_oracle_golden.py)")
+        rehearse = None
+        if rehearsal:
+            # the whole sequence in ONE process on this GPU: the gathered result of the sharded run must equal it pair for pair
+            imgs_all, toks_all = synth_sequence(n * world, 0, n * world, h, w, grid, dev, seed=1234)
+            one = pipe.run(imgs_all, toks_all)
+            same = bool(torch.equal(out["all_match_count"], one["match_count"]) and torch.equal(out["all_matches"], one["matches"])
+                        and torch.equal(out["all_quality"].view(torch.int32), one["quality"].view(torch.int32)))
+            ok = ok and same
+            rehearse = {"what": f"{world} ranks sharing {torch.cuda.device_count()} GPU(s), torch.distributed on gloo with device buffers staged "
+                                "through host memory: a functional rehearsal of the N-rank path (rank-0 weight broadcast, halo, compacted "
+                                "gather), NOT a measurement",
+                        "sharded_equals_single_process": same, "pairs": int(one["match_count"].shape[0]),
+                        "matches": int(one["match_count"].sum().item()), "pairs_per_rank": out["pairs_per_rank"],
+                        "records_per_rank": out["records_per_rank"], "rehearsal_frames_per_s": round(n * world * args.steps / dt, 1)}
+            del imgs_all, toks_all, one
         mpeak = measured_mfma_peak() if world == 1 else None
         res = {
             "metric": METRIC, "value": round(n * world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
@@ -559,7 +585,12 @@ def main():
             res["tum_directory"] = dir_leg
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
-        if not ok:
+        if rehearse is not None:
+            res["rehearsal"], res["value"] = rehearse, None
+            res["parallelism_backend"] = "gloo (rehearsal)"
+        elif world > 1:
+            res["parallelism_backend"] = "nccl (RCCL)"
+        if not ok and rehearse is None:
             # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
             res["value_unverified"], res["value"] = res["value"], None
         print(json.dumps(res))

@@ -34,10 +34,53 @@ def shard_bounds(n_frames: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _host_staged(group=None) -> bool:
+    """True on a backend without device-memory transport (gloo: the CPU tests, and the shared-GPU rehearsal of bench.py):
+    CUDA tensors then travel through host memory.  On nccl (= RCCL over xGMI) device buffers are handed over as they are."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _broadcast(t: torch.Tensor, src: int, group=None):
+    if t.is_cuda and _host_staged(group):
+        c = t.cpu()
+        dist.broadcast(c, src=src, group=group)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+class _P2P:
+    """One batch of isend / irecv (batch_isend_irecv); CUDA tensors are staged through host memory where _host_staged()."""
+
+    def __init__(self, group=None):
+        self.group, self.ops, self.after, self.reqs = group, [], [], []
+        self.staged = _host_staged(group)
+
+    def send(self, t: torch.Tensor, dst: int):
+        self.ops.append(dist.P2POp(dist.isend, t.cpu() if (t.is_cuda and self.staged) else t, dst, self.group))
+
+    def recv(self, t: torch.Tensor, src: int):
+        if t.is_cuda and self.staged:
+            buf = torch.empty(t.shape, dtype=t.dtype)
+            self.after.append((t, buf))
+            t = buf
+        self.ops.append(dist.P2POp(dist.irecv, t, src, self.group))
+
+    def post(self):
+        self.reqs = dist.batch_isend_irecv(self.ops) if self.ops else []
+        return self
+
+    def wait(self):
+        for req in self.reqs:
+            req.wait()
+        for t, buf in self.after:
+            t.copy_(buf)
+
+
 def broadcast_weights(tensors: list, src: int = 0, group=None):
     """Rank `src` owns the checkpoint; everyone else receives the packed device buffers (6.7 MB fp32, once)."""
     for t in tensors:
-        dist.broadcast(t, src=src, group=group)
+        _broadcast(t, src, group)
 
 
 def pipeline_from_rank0(cfg, selector_state: dict | None, refiner_state: dict | None, device, bn_state: dict | None = None,
@@ -56,7 +99,7 @@ def pipeline_from_rank0(cfg, selector_state: dict | None, refiner_state: dict | 
         head[0] = int(tuple(selector_state["conv.0.weight"].shape)[0])
         head[1] = refiner_weight_list(refiner_state)[1]
         head[2] = 1
-    dist.broadcast(head, src=src, group=group)
+    _broadcast(head, src, group)
     hidden, n_blocks, ok = (int(v) for v in head.tolist())
     if not ok:
         raise RuntimeError("weight broadcast header missing")
@@ -138,15 +181,15 @@ class ShardedSequenceRunner:
         """Post the sends of my first `spacing` frames (`send`: name -> (sp, ...) tensor) to rank-1 and the receives from
         rank+1 into `recv` (name -> (sp, ...) view of the block buffer's halo rows); returns the requests."""
         r, w = self.rank, self.world
-        ops = []
+        p2p = _P2P(self.group)
         for name, t in send.items():
             if t is None:
                 continue
             if r > 0:
-                ops.append(dist.P2POp(dist.isend, t, r - 1, self.group))
+                p2p.send(t, r - 1)
             if r < w - 1:
-                ops.append(dist.P2POp(dist.irecv, recv[name], r + 1, self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+                p2p.recv(recv[name], r + 1)
+        return p2p.post()
 
     # ------------------------------------------------------------------------------------------------- run
     def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True) -> dict:
@@ -177,8 +220,7 @@ class ShardedSequenceRunner:
                     ex_tail = self.extract_fn(tokens_local[sp:], img(sp, n))
                     for k, v in full.items():
                         v[sp:n] = ex_tail[k]
-            for req in reqs:
-                req.wait()
+            reqs.wait()
             ex = {k: v[:n] for k, v in full.items()}
             fields = {k: full.get(k) for k in names}      # n + halo rows
         m = self.match_fn(fields["descriptors"], fields["scores"], fields["intensity"], sp)   # every local i that has a partner
@@ -197,6 +239,8 @@ class ShardedSequenceRunner:
         rec, n_valid = compact_records(m["matches"], m["quality"], m["match_count"])      # LOCAL pair indices
         dev = rec.device
         sizes = torch.stack([torch.tensor(m["match_count"].shape[0], dtype=torch.int64, device=dev), n_valid])
+        if sizes.is_cuda and _host_staged(self.group):
+            sizes = sizes.cpu()
         all_sizes = [torch.zeros_like(sizes) for _ in range(w)]
         dist.all_gather(all_sizes, sizes, group=self.group)
         table = torch.stack(all_sizes).tolist()       # the step's one host synchronisation: [[pairs, records], ...] per rank
@@ -207,13 +251,12 @@ class ShardedSequenceRunner:
         if r == 0:
             buf = torch.empty((sum(nrec), 4), dtype=torch.int32, device=dev)
             buf[: nrec[0]] = rec[: nrec[0]]
-            ops, off = [], nrec[0]
+            p2p, off = _P2P(self.group), nrec[0]
             for src in range(1, w):
                 if nrec[src]:
-                    ops.append(dist.P2POp(dist.irecv, buf[off:off + nrec[src]], src, self.group))
+                    p2p.recv(buf[off:off + nrec[src]], src)
                 off += nrec[src]
-            for req in (dist.batch_isend_irecv(ops) if ops else []):
-                req.wait()
+            p2p.post().wait()
             # local -> sequence pair numbers: rank src's pairs start at the sum of the pair counts of the ranks before it
             off, first = nrec[0], pairs[0]
             for src in range(1, w):
@@ -223,6 +266,7 @@ class ShardedSequenceRunner:
             res["records"] = buf
             res.update(expand_records(buf, sum(pairs), K))
         elif nrec[r]:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec[: nrec[r]].contiguous(), 0, self.group)]):
-                req.wait()
+            p2p = _P2P(self.group)
+            p2p.send(rec[: nrec[r]].contiguous(), 0)
+            p2p.post().wait()
         return res

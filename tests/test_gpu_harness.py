@@ -259,3 +259,25 @@ def test_pipeline_raises_when_k_cannot_be_served(T):
     toks = T.from_numpy(synth.token_sequence(2, 14)).cuda()
     with pytest.raises(RuntimeError, match="out of range"):
         p14.extract(toks)
+
+
+def test_two_rank_rehearsal_on_one_gpu(T):
+    """The whole N-rank path of bench.py - it starts its own ranks, rank 0 packs and broadcasts the weights, boundary frames go
+    first, halo exchange, compacted gather to rank 0 - rehearsed with two ranks sharing this GPU over gloo (RCCL refuses two ranks
+    on one GPU; device buffers are staged through host memory): the gathered result equals the single-process pass pair for
+    pair, and the line carries no value (a rehearsal is not a measurement)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--frames", "21",
+                        "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["value"] is None and d["n_gpus"] == 2 and d["n_ranks_seen"] == 2
+    assert d["frame_ranges"] == [[0, 21], [21, 42]]
+    assert d["parity"]["bit_exact"] and d["parity"]["pairs_checked"] == 2
+    reh = d["rehearsal"]
+    assert reh["sharded_equals_single_process"] and reh["pairs"] == 41 and reh["pairs_per_rank"] == [21, 20] and reh["matches"] > 0
