@@ -14,7 +14,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-extern long long g_sslam_launches;
+extern long long g_sslam_launches;      // diagnostic launch counter (sslam_launch_count): relaxed atomic adds, so that concurrent
+                                        // callers on distinct streams never race on it - it is the library's only mutable state
+static inline void sslam_count_launches(long long n) { __atomic_fetch_add(&g_sslam_launches, n, __ATOMIC_RELAXED); }
 
 // TEST-ONLY knobs (A/B timing, forcing a launch form in the parity tests).  Each is read from the environment ONCE, when
 // the library is loaded (lib.hip), never per call; tests flip them through sslam_test_set_knob.  Product callers leave
@@ -42,7 +44,7 @@ static inline bool sslam_knob_set(int id) { return g_sslam_knob[id] != SSLAM_KNO
 
 #define SSLAM_CHECK_LAUNCH()                                   \
     do {                                                       \
-        g_sslam_launches++;                                    \
+        sslam_count_launches(1);                               \
         if (hipGetLastError() != hipSuccess) return SSLAM_E_LAUNCH; \
     } while (0)
 

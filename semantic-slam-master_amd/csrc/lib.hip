@@ -25,7 +25,7 @@ struct KnobInit {
 
 extern "C" int sslam_version(void) { return 300; }
 extern "C" const char *sslam_arch(void) { return "gfx950"; }
-extern "C" long long sslam_launch_count(void) { return g_sslam_launches; }
+extern "C" long long sslam_launch_count(void) { return __atomic_load_n(&g_sslam_launches, __ATOMIC_RELAXED); }
 
 // One caller-owned scratch buffer that serves every *_ws entry of a pipeline step enqueued on ONE stream (the stages run
 // in stream order, so they can share it): the larger of the per-entry needs.

@@ -1112,12 +1112,12 @@ static int vit_forward_impl(const float *images_chw, const bf16 *patches, int n_
         if (!patches) {
             const long long items = prow * 96;
             hipLaunchKernelGGL(im2patch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, images_chw, size, items, hbuf);
-            g_sslam_launches++;
+            sslam_count_launches(1);
         }
         launch_rt<2, 1>(ProBf16{patches ? patches : hbuf, 768}, (const bf16 *)w->patch_w, prow, VD, EpiPatch{w->patch_b, x, stats, cells, T}, st);
-        g_sslam_launches++;
+        sslam_count_launches(1);
         hipLaunchKernelGGL(prefix_rows_kernel, dim3(n_frames * VPREFIX), dim3(64), 0, st, w->prefix, T, x, stats);
-        g_sslam_launches++;
+        sslam_count_launches(1);
     }
     const float4 *st4 = (const float4 *)stats;
     const bool small = (rows + RT_BM - 1) / RT_BM * 4 <= 256;
@@ -1143,7 +1143,7 @@ static int vit_forward_impl(const float *images_chw, const bf16 *patches, int n_
             hipLaunchKernelGGL(mlp_fused_kernel, dim3((unsigned)((rows + RT_BM - 1) / RT_BM)), dim3(512), MF_LDS_BYTES, st,
                                ProLN{x, st4, ly.ln2_g, ly.ln2_b, 1e-5f}, (const bf16 *)ly.wmlp, ly.bup, (int)rows, EpiResidual{ly.bdown, x, stats});
             if (rt_stop == 3 || rt_stop == 4) break;
-            g_sslam_launches += 4;
+            sslam_count_launches(4);
             continue;
         }
         if (small)
@@ -1153,7 +1153,7 @@ static int vit_forward_impl(const float *images_chw, const bf16 *patches, int n_
         if (rt_stop == 3) break;
         launch_rt<4, 1>(ProBf16{hbuf, VMLP}, (const bf16 *)ly.wdown, rows, VD, EpiResidual{ly.bdown, x, stats}, st);
         if (rt_stop == 4) break;
-        g_sslam_launches += 5;
+        sslam_count_launches(5);
     }
     const unsigned ln_grid = (unsigned)((rows + 3) / 4);
     hipLaunchKernelGGL(ln_rows_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, (void *)tokens_out);
