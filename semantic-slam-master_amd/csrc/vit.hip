@@ -324,7 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
             for (int s = 0; s < RT_SL; s++) asm volatile("" ::"v"(acc[s]));
         } else
 #endif
+        {
+            // several column tiles per workgroup: the A fragments stay live, so the epilogue's own loads cannot go out a group early
+            if (Epi::PREFETCH && nt_per_part != 1) epi.prefetch(est, row0, nt0 + nt, lane, M);
             epi.tile(acc, est, row0, nt0 + nt, stg, vec_epi + RT_NT * nt_per_part, lane, M);
+        }
         RT_STAMP(t_e1);
         RT_ACC(p_epi, t_e1, t_e0);
     }
