@@ -34,6 +34,9 @@ WORKLOADS = {
     "fr1_xyz_50": (50, 480, 640, 448, 500),
     "fr2_desk_1024kp": (512, 480, 640, 640, 1024),
     "synthetic_2048kp": (128, 960, 1280, 960, 2048),
+    # the multi-GPU configs of BASELINE.json at their own per-GPU share (use with --gpus 4 / --gpus 8):
+    "fr3_long_office_4gpu": (647, 480, 640, 448, 500),        # configs[3]: 2 585 frames over 4 GPUs, RCCL gather of match pairs
+    "synthetic_2048kp_8gpu": (512, 960, 1280, 960, 2048),     # configs[4]: 4 096 frames of 1280 x 960 @ 2 048 keypoints over 8 GPUs
 }
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 METRIC = "frames/sec extract+match on TUM 640x480; match-index bit-exact vs CPU ref"

@@ -57,7 +57,7 @@ long long sslam_sim_argmax_workspace_bytes(int n2, int n_pairs);
 /* TEST-ONLY: override one of the load-time knobs (name = its environment variable, e.g. "SSLAM_CONV_TAIL"); unset != 0
  * restores the built-in default.  Not thread-safe against running calls; product code never calls it.  Knobs:
  * SSLAM_M1_VARIANT, SSLAM_CONV_VARIANT, SSLAM_CONV_LATENCY_ROWS, SSLAM_CONV_LAT2_ROWS, SSLAM_CONV_NO_HALO, SSLAM_CONV_TAIL,
- * SSLAM_CONVBF_NO_HALO, SSLAM_CONVBF_TAIL, SSLAM_CONVBF_VARIANT, SSLAM_VIT_NO_FUSED_MLP, SSLAM_VIT_FORM, SSLAM_BN_FORM,
+ * SSLAM_CONVBF_NO_HALO, SSLAM_CONVBF_TAIL, SSLAM_CONVBF_VARIANT, SSLAM_VIT_NO_FUSED_MLP, SSLAM_BN_FORM,
  * SSLAM_RT_STOP (csrc/common.h says what each selects). */
 int sslam_test_set_knob(const char *name, long long value, int unset);
 

@@ -32,7 +32,6 @@ enum sslam_knob_id {
     KNOB_CONVBF_TAIL,         // SSLAM_CONVBF_TAIL
     KNOB_CONVBF_VARIANT,      // SSLAM_CONVBF_VARIANT
     KNOB_VIT_NO_FUSED_MLP,    // SSLAM_VIT_NO_FUSED_MLP    the two-launch MLP
-    KNOB_VIT_FORM,            // SSLAM_VIT_FORM            A/B selector of ViT launch forms (round 3)
     KNOB_BN_FORM,             // SSLAM_BN_FORM             1: three-sweep BatchNorm kernel instead of the register-resident one
     KNOB_RT_STOP,             // SSLAM_RT_STOP             probe builds only
     KNOB_COUNT
