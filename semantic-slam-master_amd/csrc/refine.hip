@@ -182,6 +182,11 @@ __device__ unsigned long long g_probe_refine[8 * 4096];
 #define PROBE(slot, stmt) { stmt; }
 #define PROBE_END()
 #endif
+// Issue priority: a wave outside its GEMM loops (gather, LayerNorm hand-over, tile stores, epilogue) runs at priority 1, inside
+// them at 0: the arbiter otherwise serves the co-resident workgroups' back-to-back MFMAs first and a hand-over of ~1 000
+// instructions takes 40-50 k cycles; with the hint it is through sooner and back to feeding the matrix pipe (-1.5 %).
+#define PRIO_OTHER() __builtin_amdgcn_s_setprio(1)
+#define PRIO_GEMM() __builtin_amdgcn_s_setprio(0)
 enum { PR_GATHER = 0, PR_GEMM = 1, PR_LN = 2, PR_STORE = 3, PR_BARRIER = 4 };
 
 __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(const float *__restrict__ feat, int G,
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     float *H = smem, *scratch = smem + H_FLOATS;
     const int tid = threadIdx.x;
     PROBE_BEGIN();
+    PRIO_OTHER();
     // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD one contiguous range of row tiles so that the ~8
     // tiles gathering from one frame's feature map share that XCD's L2 instead of fetching the frame into all eight
     long long R0;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     // tile accesses (all waves have left the GEMM that read the tile before anyone writes it).
     float *part0 = scratch, *part1 = scratch + 128;
     f32x16 X[3], acc[3];
-    PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);)
+    PRIO_GEMM(); PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.in_w * 4, pk + L.in_b, tid, acc);) PRIO_OTHER();
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -257,14 +263,14 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
     for (int b = 0; b < L.n_blocks; b++) {
         PROBE(PR_LN, layernorm_store(H, part0, part1, pk + L.blk[b][0], pk + L.blk[b][1], tid, X);)
         PROBE(PR_BARRIER, __syncthreads();)
-        PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);)
+        PRIO_GEMM(); PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][2] * 4, pk + L.blk[b][3], tid, acc);) PRIO_OTHER();
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[t][e] = acc[t][e] > 0.0f ? acc[t][e] : 0.0f;
         PROBE(PR_LN, layernorm_store(H, part0, part1, pk + L.blk[b][4], pk + L.blk[b][5], tid, acc);)
         PROBE(PR_BARRIER, __syncthreads();)
-        PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);)
+        PRIO_GEMM(); PROBE(PR_GEMM, gemm_lds<3>(H, wrs, (int)L.blk[b][6] * 4, pk + L.blk[b][7], tid, acc);) PRIO_OTHER();
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(NTHR, WMR == 1 ? 3 : 2) void gather_refine_kernel(c
 
     // ---- output_proj + L2 normalise (:83-86; F.normalize eps 1e-12) --------------------------------------------
     f32x16 o[1];
-    PROBE(PR_GEMM, gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);)
+    PRIO_GEMM(); PROBE(PR_GEMM, gemm_lds<1>(H, wrs, (int)L.out_w * 4, pk + L.out_b, tid, o);) PRIO_OTHER();
     {
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
         float ss = 0.0f;

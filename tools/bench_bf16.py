@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import synth
 from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (experiments)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 
 def timeit(fn, n=10):
     for _ in range(3): fn()

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
+from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (experiments)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 from sslam_amd.vit import DinoV3ViT
 from sslam_amd.vit_hip import HipViT
 
@@ -14,16 +17,17 @@ vit = DinoV3ViT().cuda().eval()
 hv = HipViT(vit)
 T = 5 + (size // 16) ** 2
 flop = 12 * (T * 384 * 1152 * 2 + 2 * 6 * T * T * 64 * 2 + T * 384 * 384 * 2 + 2 * T * 384 * 1536 * 2) + (T - 5) * 768 * 384 * 2
+CH = int(os.environ.get("SSLAM_BENCH_CHUNK", "0"))      # frames per launch group (default: the whole batch in one group)
 chunks = [int(a) for a in sys.argv[2:]] or [8, 16, 32, 64, 128]
 for n in chunks:
     x = torch.randn(n, 3, size, size, device="cuda")
     for _ in range(2):
-        hv.forward_features(x, chunk=n)
+        hv.forward_features(x, chunk=CH or n)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        hv.forward_features(x, chunk=n)
+        hv.forward_features(x, chunk=CH or n)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"size {size} chunk {n:4d}: {dt*1e3:8.3f} ms  {n/dt:9.1f} frames/s  {n*flop/dt/1e12:7.1f} TFLOP/s", flush=True)
