@@ -281,3 +281,71 @@ def test_two_rank_rehearsal_on_one_gpu(T):
     assert d["parity"]["bit_exact"] and d["parity"]["pairs_checked"] == 2
     reh = d["rehearsal"]
     assert reh["sharded_equals_single_process"] and reh["pairs"] == 41 and reh["pairs_per_rank"] == [21, 20] and reh["matches"] > 0
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, "semantic-slam-master_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import torch, torch.distributed as dist
+import synth
+from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+from sslam_amd.shard import ShardedSequenceRunner, _P2P, _host_staged, pipeline_from_rank0
+
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl" and not _host_staged()
+cfg = ExtractorConfig()
+ssd, rsd = synth.selector_state(0), synth.refiner_state(0)
+pipe = pipeline_from_rank0(cfg, ssd, rsd, dev)                    # header + packed weights through ncclBroadcast
+ref = SequencePipeline(cfg, ssd, rsd, device=dev)
+for a, b in zip(pipe.weight_tensors(), ref.weight_tensors()):
+    assert torch.equal(a, b)
+n = 9
+toks = torch.from_numpy(synth.token_sequence(n, 28)).to(dev)
+imgs = torch.from_numpy(synth.image_sequence(n)).to(dev)
+# device buffers handed to RCCL as they are: a self-addressed batch of the same shapes and dtypes the halo exchange and the
+# record gather use (fp32 descriptors / scores, int32 records; sends and receives posted in ONE batch_isend_irecv)
+ex = pipe.extract(toks, imgs)
+halo = {k: torch.empty_like(ex[k][:1]) for k in ("descriptors", "scores", "intensity")}
+rec = torch.arange(4 * 37, dtype=torch.int32, device=dev).reshape(37, 4)
+rec_in = torch.empty_like(rec)
+p2p = _P2P()
+for k, v in halo.items():
+    p2p.send(ex[k][:1], 0)
+    p2p.recv(v, 0)
+p2p.send(rec, 0)
+p2p.recv(rec_in, 0)
+p2p.post().wait()
+torch.cuda.synchronize()
+for k, v in halo.items():
+    assert torch.equal(v, ex[k][:1]), k
+assert torch.equal(rec_in, rec)
+sizes = torch.tensor([5, 7], dtype=torch.int64, device=dev)
+got = [torch.zeros_like(sizes)]
+dist.all_gather(got, sizes)
+assert got[0].tolist() == [5, 7]
+out = ShardedSequenceRunner(pipe.extract, pipe.match, spacing=1).run(toks, imgs)
+one = ref.run(imgs, toks)
+for k in ("idx", "descriptors", "matches", "quality", "match_count"):
+    assert torch.equal(out[k], one[k]), k
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-one-rank ok")
+'''
+
+
+def test_rccl_group_of_one_rank(T):
+    """What CAN be run of the RCCL path on a one-GPU box: a process group on backend "nccl" (= RCCL) with one rank.  The weight
+    header + packed buffers go through the broadcast, the size exchange through all_gather, and device buffers of the halo /
+    record shapes and dtypes through one batch_isend_irecv addressed to the rank itself - no host staging (that is the gloo
+    rehearsal's).  Two ranks on two GPUs over xGMI remain the driver's round-end run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl-one-rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
