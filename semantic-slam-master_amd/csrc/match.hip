@@ -62,11 +62,14 @@ struct Stager {
 };
 
 // monotone 64-bit image of (similarity, query index): "larger value, then lower index" is one unsigned compare, so the
-// column direction can be reduced with max() in any order (lanes, waves, workgroups) and still give the first maximum
-__device__ __forceinline__ unsigned long long sim_key(float v, int i) {
-    unsigned u = __float_as_uint(v + 0.0f);                 // -0 -> +0: equal under the float compare of the reference
-    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
-    return ((unsigned long long)u << 32) | (unsigned)(~i);
+// column direction can be reduced with max() in any order (lanes, waves, workgroups) and still give the first maximum.
+// qoff = +0 for a lane that holds a query (the add also turns -0 into +0: equal under the float compare of the reference),
+// -inf for a lane beyond the last query: its key is then below every key of a finite similarity and never wins - no select.
+// nqi = ~(query index), the low word.
+__device__ __forceinline__ unsigned long long sim_key(float v, float qoff, unsigned nqi) {
+    unsigned u = __float_as_uint(v + qoff);
+    u ^= (unsigned)((int)u >> 31) | 0x80000000u;
+    return ((unsigned long long)u << 32) | nqi;
 }
 
 // The reduction of one finished 32 x 32 tile, cut into 24 micro-steps so that the kernel can issue a few of them behind
@@ -74,55 +77,69 @@ __device__ __forceinline__ unsigned long long sim_key(float v, int i) {
 //   0..7    row scan of accumulator rows 2 STEP, 2 STEP + 1: register-local first-max (+ runner-up) per query lane
 //   8..15   column butterfly, xor 16: builds the 64-bit keys of rows i, i + 8 and keeps one of them (reduce-scatter)
 //   16..19  xor 8 (4 exchanges), 20..21 xor 4, 22 xor 2, 23 xor 1 -> kk = key of accumulator row crow((r >> 1) & 15, h)
+// Every vector instruction here takes issue time the fp32 MFMAs of the same SIMD cannot use (PMC: matrix time + vector time
+// add up to the kernel time), so the steps are written for instruction COUNT:
+//   * the row scan is compare + two selects per score (+ one v_med3 for the runner-up, only in the form that returns it):
+//     the winner's row is kept as a stage-local literal (32 CT + its accumulator row, an inline constant of the select) and
+//     turned into a candidate index once per stage; rows beyond nc are masked only in the LAST stage (MASKED);
+//   * the xor-16 exchange is v_permlane16_swap on the two key halves: afterwards every lane holds (own key, partner's key)
+//     of the row it keeps - no keep / send selects, no LDS crossbar.
 struct RowBest {
     float best, second;
-    int besti;
+    int besti, li;          // li: literal of the stage's winner so far, -1 = the running best is from an earlier stage
 };
-template <int STEP, bool ONEPASS>
-__device__ __forceinline__ void red_step(const f32x16 &acc, int jbase, int nc, int r, int h, bool qok, int qi, RowBest &rb,
+template <int STEP, int CT, bool ONEPASS, bool MASKED, bool SECOND>
+__device__ __forceinline__ void red_step(const f32x16 &acc, int sbase, int nc, int r, int h, float qoff, unsigned nqi, RowBest &rb,
                                          unsigned long long (&k)[8], unsigned long long &kk, int &jj) {
     if constexpr (STEP < 8) {
+        if constexpr (STEP == 0 && CT == 0) rb.li = -1;
 #pragma unroll
         for (int e = 2 * STEP; e < 2 * STEP + 2; e++) {   // branch-free form of: if (v > best) {second = best; best = v; besti = j;}
-            const int j = jbase + crow(e, h);             //                  else if (v > second) second = v;      (rows j >= nc skipped)
-            const float v = j < nc ? acc[e] : -INFINITY;
+                                                          //                  else if (v > second) second = v;      (rows j >= nc skipped)
+            const int lit = 32 * CT + (e & 3) + 8 * (e >> 2);      // j = sbase + lit + 4 h, increasing in (CT, e)
+            float v = acc[e];
+            if constexpr (MASKED) v = sbase + lit + 4 * h < nc ? v : -INFINITY;
             const bool gt = v > rb.best;
-            rb.second = gt ? rb.best : fmaxf(rb.second, v);
-            rb.besti = gt ? j : rb.besti;
+            // best >= second always: the median of (v, best, second) is best if v beats it, else max(second, v)
+            if constexpr (SECOND) rb.second = __builtin_amdgcn_fmed3f(v, rb.best, rb.second);
+            rb.li = gt ? lit : rb.li;
             rb.best = gt ? v : rb.best;
         }
+        if constexpr (STEP == 7 && CT == 1) rb.besti = rb.li >= 0 ? sbase + 4 * h + rb.li : rb.besti;
     } else if constexpr (!ONEPASS) {
     } else if constexpr (STEP < 16) {
         constexpr int i = STEP - 8;
-        const bool up = (r & 16) != 0;
-        unsigned long long lo = qok ? sim_key(acc[i], qi) : 0ull, hi = qok ? sim_key(acc[i + 8], qi) : 0ull;
-        asm("" : "+v"(lo), "+v"(hi));          // keeps the selects from being folded into a dynamic vector index
-        const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
-        const unsigned long long o = __shfl_xor(send, 16);
-        k[i] = keep > o ? keep : o;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long lo = sim_key(acc[i], qoff, nqi), hi = sim_key(acc[i + 8], qoff, nqi);
+        // rows of 16 lanes: the odd rows of the first operand change places with the even rows of the second, so a lane of an
+        // even row (keeps i) ends up with (own lo, partner's lo) and a lane of an odd row (keeps i + 8) with (partner's hi, own hi)
+        const u32x2 w0 = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)hi, false, false);
+        const u32x2 w1 = __builtin_amdgcn_permlane16_swap((unsigned)(lo >> 32), (unsigned)(hi >> 32), false, false);
+        const unsigned long long a = ((unsigned long long)w1[0] << 32) | w0[0], b = ((unsigned long long)w1[1] << 32) | w0[1];
+        k[i] = a > b ? a : b;
     } else if constexpr (STEP < 23) {
         constexpr int m = STEP < 20 ? 4 : (STEP < 22 ? 2 : 1);
         constexpr int i = STEP < 20 ? STEP - 16 : (STEP < 22 ? STEP - 20 : 0);
         const bool up = (r & (2 * m)) != 0;
         unsigned long long lo = k[i], hi = k[i + m];
-        asm("" : "+v"(lo), "+v"(hi));
+        asm("" : "+v"(lo), "+v"(hi));          // keeps the selects from being folded into a dynamic vector index
         const unsigned long long keep = up ? hi : lo, send = up ? lo : hi;
         const unsigned long long o = __shfl_xor(send, 2 * m);
         k[i] = keep > o ? keep : o;
     } else {
         const unsigned long long o = __shfl_xor(k[0], 1);
         kk = k[0] > o ? k[0] : o;
-        jj = jbase + crow((r >> 1) & 15, h);       // the accumulator row this lane pair ended up holding
+        jj = sbase + 32 * CT + crow((r >> 1) & 15, h);       // the accumulator row this lane pair ended up holding
     }
 }
 // micro-steps [FIRST, FIRST + N) of the 48 of a stage (two tiles)
-template <int FIRST, int N, bool ONEPASS>
-__device__ __forceinline__ void red_steps(const f32x16 (&acc)[2], int s, int nc, int r, int h, bool qok, int qi, RowBest &rb,
+template <int FIRST, int N, bool ONEPASS, bool MASKED, bool SECOND>
+__device__ __forceinline__ void red_steps(const f32x16 (&acc)[2], int s, int nc, int r, int h, float qoff, unsigned nqi, RowBest &rb,
                                           unsigned long long (&k)[2][8], unsigned long long (&kk)[2], int (&jj)[2]) {
     if constexpr (N > 0) {
         constexpr int ct = FIRST / 24;
-        red_step<FIRST % 24, ONEPASS>(acc[ct], s * CB + ct * 32, nc, r, h, qok, qi, rb, k[ct], kk[ct], jj[ct]);
-        red_steps<FIRST + 1, N - 1, ONEPASS>(acc, s, nc, r, h, qok, qi, rb, k, kk, jj);
+        red_step<FIRST % 24, ct, ONEPASS, MASKED, SECOND>(acc[ct], s * CB, nc, r, h, qoff, nqi, rb, k[ct], kk[ct], jj[ct]);
+        red_steps<FIRST + 1, N - 1, ONEPASS, MASKED, SECOND>(acc, s, nc, r, h, qoff, nqi, rb, k, kk, jj);
     }
 }
 
@@ -131,7 +148,8 @@ __device__ __forceinline__ void red_steps(const f32x16 (&acc)[2], int s, int nc,
 // ONEPASS = true:  grid (query blocks, 1, pairs) - S is evaluated ONCE; the column direction (nn21) is reduced over the
 //                  32 query lanes of each half-wave by a reduce-scatter butterfly on sim_key()s and merged across waves
 //                  and workgroups with a 64-bit atomic max into `keys` (n_pairs x n2, zeroed), decoded by keys_decode_kernel.
-template <bool ONEPASS>
+// SECOND: also the runner-up of the row direction (second12; the ratio-test matchers M2 / M4).
+template <bool ONEPASS, bool SECOND>
 __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restrict__ desc1, long long stride1, int n1,
                                                             const float *__restrict__ desc2, long long stride2, int n2,
                                                             int *__restrict__ nn12, float *__restrict__ s12,
@@ -177,7 +195,9 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
     sc.store(Cs, tid);
     __syncthreads();
 
-    RowBest rb = {-INFINITY, -INFINITY, 0x7fffffff};     // second: best of the row once the winner is removed
+    RowBest rb = {-INFINITY, -INFINITY, 0x7fffffff, -1};     // second: best of the row once the winner is removed
+    const float qoff = qok ? 0.0f : -INFINITY;
+    const unsigned nqi = ~(unsigned)qi;
     const int nstage = (nc + CB - 1) / CB;
 
     // A stage = 128 MFMAs (two 32 x 32 tiles against the wave's queries) + its reduction (row scan; in the single-evaluation
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
 #define M1_SLOT(g_)                                                                                                   \
         M1_MMA(g_, A, acc)                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        red_steps<3 * (g_), 3, ONEPASS>(held, s - 1, nc, r, h, qok, qi, rb, kq, kk, jj);                              \
+        red_steps<3 * (g_), 3, ONEPASS, false, SECOND>(held, s - 1, nc, r, h, qoff, nqi, rb, kq, kk, jj);                              \
         __builtin_amdgcn_sched_barrier(0);
         M1_SLOT(0) M1_SLOT(1) M1_SLOT(2) M1_SLOT(3) M1_SLOT(4) M1_SLOT(5) M1_SLOT(6) M1_SLOT(7)
         M1_SLOT(8) M1_SLOT(9) M1_SLOT(10) M1_SLOT(11) M1_SLOT(12) M1_SLOT(13) M1_SLOT(14) M1_SLOT(15)
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
     {
         unsigned long long kk[2] = {0ull, 0ull};
         int jj[2] = {0, 0};
-        red_steps<0, 48, ONEPASS>(held, nstage - 1, nc, r, h, qok, qi, rb, kq, kk, jj);
+        red_steps<0, 48, ONEPASS, true, SECOND>(held, nstage - 1, nc, r, h, qoff, nqi, rb, kq, kk, jj);    // the last stage: rows beyond nc masked
         commit(kk, jj);
     }
     float best = rb.best, second = rb.second;
@@ -375,8 +395,13 @@ extern "C" int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1
         unsigned long long *keys = (unsigned long long *)workspace;      // CALLER-OWNED scratch: the library allocates nothing
         if (hipMemsetAsync(keys, 0, (size_t)need, st) != hipSuccess) return SSLAM_E_LAUNCH;
         const int qb1 = (n1 + QB - 1) / QB;
-        hipLaunchKernelGGL(sim_argmax_kernel<true>, dim3((unsigned)((n_pairs + 7) / 8 * 8 * qb1), 1, 1), dim3(NTM), 0, st, desc1, stride1, n1,
-                           desc2, stride2, n2, nn12, s12, nn21, s21, second12, keys, n_pairs, qb1);
+        const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * qb1), 1, 1);
+        if (second12)
+            hipLaunchKernelGGL((sim_argmax_kernel<true, true>), grid, dim3(NTM), 0, st, desc1, stride1, n1, desc2, stride2, n2, nn12, s12,
+                               nn21, s21, second12, keys, n_pairs, qb1);
+        else
+            hipLaunchKernelGGL((sim_argmax_kernel<true, false>), grid, dim3(NTM), 0, st, desc1, stride1, n1, desc2, stride2, n2, nn12, s12,
+                               nn21, s21, second12, keys, n_pairs, qb1);
         SSLAM_CHECK_LAUNCH();
         const long long n = (long long)n_pairs * n2;
         hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
@@ -385,8 +410,13 @@ extern "C" int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1
     }
     const int nmax = n1 > n2 ? n1 : n2;
     const int qbm = (nmax + QB - 1) / QB;
-    hipLaunchKernelGGL(sim_argmax_kernel<false>, dim3((unsigned)((n_pairs + 7) / 8 * 8 * qbm), 2, 1), dim3(NTM), 0, st, desc1, stride1, n1,
-                       desc2, stride2, n2, nn12, s12, nn21, s21, second12, nullptr, n_pairs, qbm);
+    const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8 * qbm), 2, 1);
+    if (second12)
+        hipLaunchKernelGGL((sim_argmax_kernel<false, true>), grid, dim3(NTM), 0, st, desc1, stride1, n1, desc2, stride2, n2, nn12, s12, nn21,
+                           s21, second12, nullptr, n_pairs, qbm);
+    else
+        hipLaunchKernelGGL((sim_argmax_kernel<false, false>), grid, dim3(NTM), 0, st, desc1, stride1, n1, desc2, stride2, n2, nn12, s12, nn21,
+                           s21, second12, nullptr, n_pairs, qbm);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }
