@@ -256,10 +256,14 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
         M1_SLOT(0) M1_SLOT(1) M1_SLOT(2) M1_SLOT(3) M1_SLOT(4) M1_SLOT(5) M1_SLOT(6) M1_SLOT(7)
         M1_SLOT(8) M1_SLOT(9) M1_SLOT(10) M1_SLOT(11) M1_SLOT(12) M1_SLOT(13) M1_SLOT(14) M1_SLOT(15)
 #undef M1_SLOT
-        commit(kk, jj);
         held[0] = acc[0];
         held[1] = acc[1];
         if (s + 1 < nstage) sc.store(Cs + ((s + 1) & 1) * CB * LDD, tid);
+        // the atomics go out AFTER the tile stores: memory operations complete in order in the wave's counter, and the wait for the
+        // tile's loads in front of the stores would otherwise also wait for two memory-side atomics (a round trip to the
+        // memory-side atomic unit) in every stage; issued here they are in flight across the barrier and the next stage
+        __builtin_amdgcn_sched_barrier(0);
+        commit(kk, jj);
         __syncthreads();
     }
 #undef M1_MMA

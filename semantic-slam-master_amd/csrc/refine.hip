@@ -103,18 +103,35 @@ __device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t 
 }
 
 // this wave's 32 rows x 96 columns (transposed accumulators) -> activation tile (KP8 positions): the four consecutive
-// columns of an accumulator quad land as two 8-byte pairs
+// columns c .. c + 3 of an accumulator quad land at floats 0, 4, 1, 5 of their group of 8.  Two ds_write2_b32 per quad, written
+// as such: from C++ stores hipcc builds 8-byte writes of the pairs (c, c + 2), (c + 1, c + 3), which need those pairs in adjacent
+// registers - six v_mov per quad, and every vector instruction of a hand-over is issue time the matrix pipe does not get.
+// (The compiler does not count these LDS operations: lds_quads_done() waits for them before the barrier that publishes the tile.)
+template <int V>
+struct IC {
+    static constexpr int value = V;
+};
+template <int DW>
+__device__ __forceinline__ void store_quad(unsigned row_lds, float y0, float y1, float y2, float y3) {
+    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(row_lds), "v"(y0), "v"(y1), "n"(DW), "n"(DW + 4) : "memory");
+    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(row_lds), "v"(y2), "v"(y3), "n"(DW + 1), "n"(DW + 5) : "memory");
+}
+__device__ __forceinline__ void lds_quads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float *)p;
+}
+template <int I>
+__device__ __forceinline__ void store_rows_from(unsigned row_lds, const f32x16 (&v)[3]) {
+    if constexpr (I < 12) {
+        constexpr int t = I / 4, q = I % 4;
+        store_quad<32 * t + 8 * q>(row_lds, v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]);
+        store_rows_from<I + 1>(row_lds, v);
+    }
+}
 __device__ __forceinline__ void store_rows(float *H, int tid, const f32x16 (&v)[3]) {
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
-    float *row = H + r * LDH + wn * 96 + 2 * h;
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float *g = row + t * 32 + 8 * q;
-            *reinterpret_cast<float2 *>(g) = make_float2(v[t][4 * q], v[t][4 * q + 2]);
-            *reinterpret_cast<float2 *>(g + 4) = make_float2(v[t][4 * q + 1], v[t][4 * q + 3]);
-        }
+    store_rows_from<0>(lds_addr(H + r * LDH + wn * 96 + 2 * h), v);
+    lds_quads_done();
 }
 
 // lane-local partial p of one row statistic -> its total over the row's 384 (or 128) columns, in the canonical tree of the
@@ -130,9 +147,22 @@ __device__ __forceinline__ float row_total(float p, float *part, int tid) {
 
 // LayerNorm(384) of the wave's transposed accumulators (row m = r per lane), written to the activation tile as the next
 // GEMM's operand; v itself (the residual identity, where it is one) stays untouched in registers.  Oracle: layernorm384.
+// The affine parameters of the lane's 48 columns are 12 (gamma, beta) quads from the L2-resident packed buffer.  They are
+// requested THREE QUADS AHEAD through a register ring, the first three before the row statistics: loaded where they are used,
+// hipcc waits for each pair right behind its request - 12 serial L2 round trips per call, most of a hand-over's 40-50 k cycles.
 __device__ __forceinline__ void layernorm_store(float *H, float *part0, float *part1, const float *__restrict__ gam,
                                                 const float *__restrict__ bet, int tid, const f32x16 (&v)[3]) {
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, wn = wave & 3;
+    const float *gp = gam + wn * 96 + 4 * h, *bp = bet + wn * 96 + 4 * h;      // quad i = (t, qd) = (i / 4, i % 4) at + 32 t + 8 qd
+    constexpr int AHEAD = 3;
+    f32x4 g4[AHEAD], b4[AHEAD];
+#define LN_REQ(i_)                                                                                       \
+    {                                                                                                    \
+        g4[(i_) % AHEAD] = *reinterpret_cast<const f32x4 *>(gp + 32 * ((i_) / 4) + 8 * ((i_) % 4));      \
+        b4[(i_) % AHEAD] = *reinterpret_cast<const f32x4 *>(bp + 32 * ((i_) / 4) + 8 * ((i_) % 4));      \
+    }
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) LN_REQ(i)
     float s = 0.0f;
 #pragma unroll
     for (int t = 0; t < 3; t++)
@@ -149,20 +179,21 @@ __device__ __forceinline__ void layernorm_store(float *H, float *part0, float *p
         }
     const float var = row_total(q, part1, tid) / 384.0f;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    float *row = H + r * LDH + wn * 96 + 2 * h;
+    const unsigned row_lds = lds_addr(H + r * LDH + wn * 96 + 2 * h);
+    auto quad = [&](auto ic) {
+        constexpr int i = decltype(ic)::value, t = i / 4, qd = i % 4;
+        const f32x4 gq = g4[i % AHEAD], bq = b4[i % AHEAD];
+        float y[4];
 #pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-            const int n0 = wn * 96 + t * 32 + 8 * qd + 4 * h;
-            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gam + n0), b4 = *reinterpret_cast<const f32x4 *>(bet + n0);
-            float y[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) y[i] = __builtin_fmaf((v[t][4 * qd + i] - mean) * rstd, g4[i], b4[i]);
-            float *g = row + t * 32 + 8 * qd;
-            *reinterpret_cast<float2 *>(g) = make_float2(y[0], y[2]);
-            *reinterpret_cast<float2 *>(g + 4) = make_float2(y[1], y[3]);
-        }
+        for (int j = 0; j < 4; j++) y[j] = __builtin_fmaf((v[t][4 * qd + j] - mean) * rstd, gq[j], bq[j]);
+        if constexpr (i + AHEAD < 12) LN_REQ(i + AHEAD)
+        __builtin_amdgcn_sched_barrier(0);      // keeps the request of quad i + 3 in front of the arithmetic of quad i + 1
+        store_quad<32 * t + 8 * qd>(row_lds, y[0], y[1], y[2], y[3]);
+    };
+    quad(IC<0>{}); quad(IC<1>{}); quad(IC<2>{}); quad(IC<3>{}); quad(IC<4>{}); quad(IC<5>{});
+    quad(IC<6>{}); quad(IC<7>{}); quad(IC<8>{}); quad(IC<9>{}); quad(IC<10>{}); quad(IC<11>{});
+    lds_quads_done();
+#undef LN_REQ
 }
 
 // Optional phase timers (build with -DSSLAM_CLOCK_PROBE, read with tools/clock_probe.py): wave 0 of the first 4096 workgroups
