@@ -14,11 +14,10 @@
 // the two half-waves are merged at the end (value, then lower index).
 // A workgroup is 4 waves = 128 queries; every wave keeps ITS 32 queries in registers for the whole kernel (the B operand
 // of v_mfma_f32_32x32x2_f32 is one VGPR per k pair: 64 VGPRs for d = 128), so LDS holds only the double-buffered
-// candidate tiles (2 x 33 KB) and TWO workgroups share a CU.  That is the point: the reduction of a stage (row scan +
-// the 64-bit key butterfly of the single-evaluation form, ~1 100 vector instructions per wave) follows its 128 MFMAs in
-// every wave of a workgroup at the same time - with one workgroup per CU the matrix pipe idled through every reduction
-// (measured 0.50 ms, of it 0.09 for the butterfly and 0.14 for the unoverlapped prologue / staging); two independent
-// workgroups drift apart and fill each other's gaps.
+// candidate tiles (2 x 33 KB) and TWO workgroups share a CU.  The reduction of a stage (row scan + the 64-bit key butterfly of
+// the single-evaluation form: ~550 vector instructions per wave after the round-3 diet, 1 100 before) follows its 128 MFMAs
+// in every wave of a workgroup at the same time; on this chip the fp32 matrix time and the vector time of a SIMD ADD UP (PMC),
+// so what counts is the number of vector instructions per MFMA, not how they are overlapped - see red_step.
 // Roofline: MFMA-bound (2 * n1 * n2 * 128 * 2 FLOP per pair incl. both directions; 128 MFLOP at 500 keypoints).
 #include "common.h"
 
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
     const int nstage = (nc + CB - 1) / CB;
 
     // A stage = 128 MFMAs (two 32 x 32 tiles against the wave's queries) + its reduction (row scan; in the single-evaluation
-    // form also the column butterfly on 64-bit keys): ~1 100 vector instructions that depend on the finished tiles.  Run one
+    // form also the column butterfly on 64-bit keys): ~550 vector instructions that depend on the finished tiles.  Run one
     // after the other, the matrix pipe idles through every reduction - and a second workgroup on the CU does not fill the gap:
     // two waves sharing a pipe fairly finish their MFMA phases together, so they also reduce together (PMC: pipe 54 % busy,
     // MFMA + VALU time adding up to the kernel time).  The loop is therefore software-pipelined INSIDE the wave, by hand:

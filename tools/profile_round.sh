@@ -54,6 +54,8 @@ python $ROOT/tools/refine_rounds.py >> $OUT/${TAG}_rounds.txt 2>/dev/null
 python $ROOT/tools/vit_streams.py 82 8 >> $OUT/${TAG}_rounds.txt 2>/dev/null
 echo "[8] round-3 additions: A2 at the three grids, host -> device feed (sweep + event timeline), other workloads"
 python $ROOT/tools/bn_bench.py > $OUT/${TAG}_bn_grids.txt 2>/dev/null
+python $ROOT/tools/m1_bench.py > $OUT/${TAG}_m1_shapes.txt 2>/dev/null
+python $ROOT/tools/refine_bench.py > $OUT/${TAG}_refine_entries.txt 2>/dev/null
 python $ROOT/tools/upload_sweep.py > $OUT/${TAG}_upload_sweep.txt 2>/dev/null
 python $ROOT/tools/upload_timeline.py 307 > $OUT/${TAG}_upload_timeline.txt 2>/dev/null
 for wl in fr1_xyz_50 fr2_desk_1024kp synthetic_2048kp; do
