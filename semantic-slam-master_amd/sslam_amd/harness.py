@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 import matching
-from .pipeline import ExtractorConfig, SequencePipeline
+from . import lib
+from .pipeline import N_PREFIX, ExtractorConfig, SequencePipeline
 
 
 class SequenceMatcher:
@@ -288,6 +289,35 @@ def chunk_bounds(n: int, chunk: int, first: int | None = None) -> list:
 
 
 @torch.no_grad()
+def _push_vit_groups(pipe: SequencePipeline, seq: "StreamingSequence", feeder: "FrameFeeder", n: int, chunk: int,
+                     group: int | None = None):
+    """ViT-inside feed loop: the ViT runs chunk by chunk as the uploads arrive (its launch group, 82 frames at 448 x 448), but
+    the authored stages run over GROUPS of chunks - an 82-frame extraction is 1.67 workgroup rounds of the descriptor MLP and
+    one partial round of the conv; half a sequence at a time they run at their large-launch rates.  Tokens of a group collect in
+    one buffer; its pixels are one contiguous view of the feeder's sequence-sized device buffer (ring mode, i.e. sequences
+    beyond FrameFeeder.max_bytes: chunk by chunk as before)."""
+    cur = torch.cuda.current_stream(pipe.device)
+    if group is None:
+        group = min(pipe.launch_group(), max(2 * chunk, -(-((n + 1) // 2) // chunk) * chunk))
+    grouped = feeder.whole and group > chunk
+    t_tok = N_PREFIX + pipe.cfg.grid ** 2
+    tok, off, g0 = None, 0, 0
+    for a, b, img, ready in feeder:
+        cur.wait_event(ready)
+        if not grouped:
+            seq.push(pipe.tokens_from_images(img), img)
+            continue
+        if tok is None:
+            tok = torch.empty((group, t_tok, lib.C_FEAT), dtype=torch.float32, device=pipe.device)
+        if off == 0:
+            g0 = a
+        pipe.tokens_from_images(img, out=tok[off:off + b - a])
+        off += b - a
+        if b == n or off + chunk > group:
+            seq.push(tok[:off], feeder.dev[g0:b])
+            off = 0
+
+
 def run_frames(pipe: SequencePipeline, n: int, h: int, w: int, spacings=(1,), tokens: torch.Tensor | None = None, fill=None,
                pinned_source: torch.Tensor | None = None, chunk: int | None = None, first_chunk: int | None = None,
                preprocess_too: bool = False, feeder_kw: dict | None = None) -> dict:
@@ -310,16 +340,14 @@ def run_frames(pipe: SequencePipeline, n: int, h: int, w: int, spacings=(1,), to
     seq.reset(capacity=n)
     feeder = FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, first_chunk), fill=fill, pinned_source=pinned_source,
                          **(feeder_kw or {}))
-    cur = torch.cuda.current_stream(pipe.device)
+    if tokens is None:
+        _push_vit_groups(pipe, seq, feeder, n, chunk)
+        return seq.result()
     for a, b, img, ready in feeder:
-        if tokens is not None:
-            # the pixels are first read by A9, the last stage of the extraction: A2..A7 run while the upload is in flight
-            seq.push(tokens[a:b], img, images_ready=ready)
-            if preprocess_too:
-                pipe.preprocess(img)
-        else:
-            cur.wait_event(ready)
-            seq.push(pipe.tokens_from_images(img), img)
+        # the pixels are first read by A9, the last stage of the extraction: A2..A7 run while the upload is in flight
+        seq.push(tokens[a:b], img, images_ready=ready)
+        if preprocess_too:
+            pipe.preprocess(img)
     return seq.result()
 
 
@@ -370,13 +398,12 @@ def run_directory(root: str, sequence: str = "", spacings=(1, 5, 10, 15, 20), pi
     seq.reset(capacity=n)
     try:
         with torch.no_grad():
-            cur = torch.cuda.current_stream(pipe.device)
-            for a, b, img, ready in FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, min(chunk, 16)), fill=fill):
-                if tokens_fn is not None:
+            feeder = FrameFeeder(n, h, w, pipe.device, chunk_bounds(n, chunk, min(chunk, 16)), fill=fill)
+            if tokens_fn is None:
+                _push_vit_groups(pipe, seq, feeder, n, chunk)
+            else:
+                for a, b, img, ready in feeder:
                     seq.push(tokens_fn(a, b), img, images_ready=ready)
-                else:
-                    cur.wait_event(ready)
-                    seq.push(pipe.tokens_from_images(img), img)
     finally:
         pool.shutdown(wait=True)
     res = seq.result()

@@ -207,14 +207,18 @@ class SequencePipeline:
         th, tv = self.tables.get(h, w, self.cfg.input_size, False)
         return lib.preprocess_u8(images_u8, self.cfg.input_size, th, tv)
 
-    def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None) -> torch.Tensor:
+    def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
         """A0 + A1: (N, H, W, 3) uint8 -> (N, 5 + G*G, 384) fp32 tokens via the HIP ViT, `vit_chunk` frames at a time.
         Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (82 frames at 448 x 448), alternating between two streams."""
         if self.vit_hip is None:
             raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
         if vit_chunk is None:
             vit_chunk = self.vit_hip.chunk_frames(self.cfg.input_size)
-        out = torch.empty((images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT), dtype=torch.float32, device=self.device)
+        shape = (images_u8.shape[0], N_PREFIX + self.cfg.grid ** 2, lib.C_FEAT)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous fp32 tensor of shape {shape}")
         # A0 runs over 16 launch groups at a time (bounds the ViT input: 1.6 GB of bf16 patch rows at 448 x 448); the ViT then
         # alternates those groups between its two streams.  A0 writes the patch-embedding operand directly (bf16 rows of 768 per
         # patch): no fp32 image, no im2patch pass; resampling ratios its tiled kernel does not cover take the fp32 image.
