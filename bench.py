@@ -195,6 +195,9 @@ def main():
                     "absent or not given: a synthetic directory of the workload's first frames is written to a temp dir")
     ap.add_argument("--tum-frames", type=int, default=128, help="frames of the directory leg (synthetic directory size / max_frames)")
     ap.add_argument("--no-directory", action="store_true", help="skip the directory -> matches leg")
+    ap.add_argument("--gather", choices=("padded", "records"), default="padded",
+                    help="N > 1: how the matches reach rank 0 - fixed-capacity arrays received in place (no device work, no host "
+                         "synchronisation) or compacted 16-byte records (half the bytes, a size exchange and an expansion on rank 0)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="functional rehearsal of the N-rank path on fewer than N GPUs: ranks share the visible GPU(s), torch.distributed "
                          "runs on gloo with device buffers staged through host memory, rank 0 checks sharded == single-process; "
@@ -285,8 +288,11 @@ def main():
 
     runner.extract_fn, runner.match_fn = extract_staged, match_staged
 
+    # every rank's block size is known from shard_bounds: the padded gather then needs no size exchange (no host synchronisation)
+    frames_per_rank = [b - a for a, b in (shard_bounds(n * world, world, r) for r in range(world))]
+
     def step():
-        return runner.run(toks, imgs)
+        return runner.run(toks, imgs, gather=args.gather, frames_per_rank=frames_per_rank)
 
     def fence():
         if world > 1:
@@ -544,11 +550,11 @@ def main():
                         and torch.equal(out["all_quality"].view(torch.int32), one["quality"].view(torch.int32)))
             ok = ok and same
             rehearse = {"what": f"{world} ranks sharing {torch.cuda.device_count()} GPU(s), torch.distributed on gloo with device buffers staged "
-                                "through host memory: a functional rehearsal of the N-rank path (rank-0 weight broadcast, halo, compacted "
-                                "gather), NOT a measurement",
+                                "through host memory: a functional rehearsal of the N-rank path (rank-0 weight broadcast, halo, "
+                                f"{args.gather} gather), NOT a measurement",
                         "sharded_equals_single_process": same, "pairs": int(one["match_count"].shape[0]),
                         "matches": int(one["match_count"].sum().item()), "pairs_per_rank": out["pairs_per_rank"],
-                        "records_per_rank": out["records_per_rank"], "rehearsal_frames_per_s": round(n * world * args.steps / dt, 1)}
+                        "gather": args.gather, "records_per_rank": out.get("records_per_rank"), "rehearsal_frames_per_s": round(n * world * args.steps / dt, 1)}
             del imgs_all, toks_all, one
         mpeak = measured_mfma_peak() if world == 1 else None
         res = {
@@ -593,6 +599,8 @@ def main():
             res["parallelism_backend"] = "gloo (rehearsal)"
         elif world > 1:
             res["parallelism_backend"] = "nccl (RCCL)"
+        if world > 1:
+            res["gather"] = args.gather
         if not ok and rehearse is None:
             # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
             res["value_unverified"], res["value"] = res["value"], None

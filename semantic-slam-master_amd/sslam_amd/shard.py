@@ -10,11 +10,18 @@ results:
      point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link).  Those frames are extracted FIRST, as their
      own small launch group, and the isend / irecv are posted before the rest of the block is extracted - the transfer
      overlaps the bulk of the extraction;
-  2. results - rank 0 alone receives the matches, COMPACTED on the sending GPU: one int32 record (pair index - local on
-     the wire, turned into the sequence's pair number on rank 0 -, idx1, idx2, quality bits) per match, 16 bytes (the padded (pairs, K, 2) int64 + (pairs, K) fp32 arrays are 20 bytes per
-     SLOT: 10 KB per pair at K = 500 whatever the match count).  Sizes are exchanged once per run (one 16-byte all-gather
-     and the only host synchronisation of the step, after everything else has been enqueued), then every rank r > 0 does
-     one send and rank 0 one recv per rank into its slice of the result.
+  2. results - rank 0 alone receives the matches, in one of two forms (`ShardedSequenceRunner.run(gather=...)`):
+     "padded" (default): every rank r > 0 sends its fixed-capacity match arrays as they are - (pairs, K, 2) int64, (pairs, K)
+     fp32, (pairs,) int32 counts; 20 bytes per SLOT, 6.1 MB per 612 pairs at K = 500 - and rank 0 receives them IN PLACE into
+     its rows of the sequence-sized result (slots past a pair's count are zero: the arrays are a pure function of the inputs).
+     No device-side work, and when the caller passes the ranks' frame counts (`frames_per_rank`, known from `shard_bounds`)
+     no size exchange and no host synchronisation: the step is enqueue-only on every rank.
+     "records": the matches are COMPACTED on the sending GPU - one int32 record (pair index - local on the wire, turned into
+     the sequence's pair number on rank 0 -, idx1, idx2, quality bits) per match, 16 bytes, about half the bytes of the padded
+     form at the bench's match rate - sizes are exchanged in one 16-byte all-gather (a host synchronisation), one send / recv
+     per rank, and rank 0 expands the records into the padded arrays.  For links where bytes, not latency, are the cost:
+     `tools/gather_cost.py` puts compaction + expansion at 0.1 + 0.3 ms per step beside a 10.8 ms step, which is why it is
+     not the default on xGMI.
 
 No all-reduce, no all-gather of payload, no weight traffic after the initial broadcast of the packed weights from rank 0
 (`pipeline_from_rank0`: one rank reads and packs the checkpoint, the others receive 6.7 MB once).
@@ -192,8 +199,15 @@ class ShardedSequenceRunner:
         return p2p.post()
 
     # ------------------------------------------------------------------------------------------------- run
-    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True) -> dict:
-        """Processes this rank's block.  Every rank must hold at least `spacing` frames."""
+    def run(self, tokens_local: torch.Tensor, images_local=None, gather_results: bool = True, gather: str = "padded",
+            frames_per_rank: list | None = None) -> dict:
+        """Processes this rank's block.  Every rank must hold at least `spacing` frames.
+        gather: "padded" | "records" (module docstring, item 2).  frames_per_rank: the frame count of every rank's block
+        (shard_bounds) - with it the padded gather needs no size exchange, hence no host synchronisation in the step."""
+        if gather not in ("padded", "records"):
+            raise ValueError(f"gather must be 'padded' or 'records', got {gather!r}")
+        if frames_per_rank is not None and (len(frames_per_rank) != self.world or int(frames_per_rank[self.rank]) != tokens_local.shape[0]):
+            raise ValueError("frames_per_rank must list every rank's frame count (this rank's entry = tokens_local.shape[0])")
         sp, n = self.spacing, tokens_local.shape[0]
         assert n >= sp, "each shard needs at least `spacing` frames"
         names = ("descriptors", "scores", "intensity")
@@ -228,12 +242,49 @@ class ShardedSequenceRunner:
         out.update(m)
         out["n_local_pairs"] = int(m["match_count"].shape[0])
         if gather_results and self.world > 1:
-            out.update(self._gather(m))
+            out.update(self._gather(m) if gather == "records" else self._gather_padded(m, n, frames_per_rank))
         return out
 
-    # ---------------------------------------------------------------------------------------------- gather
+    # ------------------------------------------------------------------------------------------- gather (padded)
+    def _gather_padded(self, m: dict, n_local: int, frames_per_rank: list | None) -> dict:
+        """The fixed-capacity match arrays of every rank -> rank 0, received in place into the sequence-sized result
+        ('all_matches', 'all_quality', 'all_match_count'); other ranks return only the pair counts."""
+        w, r, sp = self.world, self.rank, self.spacing
+        dev = m["matches"].device
+        if frames_per_rank is None:
+            # the blocks' sizes are not known here: one 8-byte all-gather (a host synchronisation; callers that know them pass them)
+            mine = torch.tensor([n_local], dtype=torch.int64, device="cpu" if _host_staged(self.group) else dev)
+            got = [torch.zeros_like(mine) for _ in range(w)]
+            dist.all_gather(got, mine, group=self.group)
+            frames_per_rank = [int(t.item()) for t in got]
+        # every local frame has a partner except the last `spacing` frames of the LAST rank (the halo covers the others)
+        pairs = [int(f) - (sp if q == w - 1 else 0) for q, f in enumerate(frames_per_rank)]
+        assert pairs[r] == m["match_count"].shape[0], (pairs, r, m["match_count"].shape)
+        res = {"pairs_per_rank": pairs}
+        names = ("matches", "quality", "match_count")
+        p2p = _P2P(self.group)
+        if r == 0:
+            total = sum(pairs)
+            full = {k: torch.empty((total,) + tuple(m[k].shape[1:]), dtype=m[k].dtype, device=dev) for k in names}
+            off = 0
+            for src in range(w):
+                for k in names:
+                    if src == 0:
+                        full[k][: pairs[0]] = m[k]
+                    elif pairs[src]:
+                        p2p.recv(full[k][off:off + pairs[src]], src)
+                off += pairs[src]
+            p2p.post().wait()
+            res.update(all_matches=full["matches"], all_quality=full["quality"], all_match_count=full["match_count"])
+        elif pairs[r]:
+            for k in names:
+                p2p.send(m[k].contiguous(), 0)
+            p2p.post().wait()
+        return res
+
+    # ------------------------------------------------------------------------------------------ gather (records)
     def _gather(self, m: dict) -> dict:
-        """Compacted match records -> rank 0 (module docstring, item 2).  Rank 0 returns the padded arrays of the whole
+        """Compacted match records -> rank 0 (module docstring, item 2, "records").  Rank 0 returns the padded arrays of the whole
         sequence ('all_matches', 'all_quality', 'all_match_count') and the raw records; other ranks only the sizes."""
         w, r = self.world, self.rank
         rec, n_valid = compact_records(m["matches"], m["quality"], m["match_count"])      # LOCAL pair indices

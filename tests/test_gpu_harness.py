@@ -318,8 +318,17 @@ for k, v in halo.items():
     p2p.recv(v, 0)
 p2p.send(rec, 0)
 p2p.recv(rec_in, 0)
+# ... and of the padded gather: int64 match slots, int32 counts, received into a slice of a larger buffer
+mt = torch.arange(3 * 500 * 2, dtype=torch.int64, device=dev).reshape(3, 500, 2)
+cn = torch.tensor([7, 0, 500], dtype=torch.int32, device=dev)
+mt_all, cn_all = torch.zeros((5, 500, 2), dtype=torch.int64, device=dev), torch.zeros(5, dtype=torch.int32, device=dev)
+p2p.send(mt, 0)
+p2p.recv(mt_all[2:5], 0)
+p2p.send(cn, 0)
+p2p.recv(cn_all[2:5], 0)
 p2p.post().wait()
 torch.cuda.synchronize()
+assert torch.equal(mt_all[2:5], mt) and torch.equal(cn_all[2:5], cn) and int(mt_all[:2].abs().sum()) == 0
 for k, v in halo.items():
     assert torch.equal(v, ex[k][:1]), k
 assert torch.equal(rec_in, rec)

@@ -60,7 +60,7 @@ def _pack(desc, sc, inten):
     return torch.from_numpy(np.concatenate([desc, sc[..., None], inten[..., None]], axis=-1))
 
 
-def _worker(rank, world, port, n_frames, spacing, q, in_place=True):
+def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="records"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -93,21 +93,28 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True):
             return extract(tokens, images)
 
         runner = ShardedSequenceRunner(extract if in_place else extract_plain, _match, spacing=spacing)
-        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]))      # no frame offset from the caller
+        # no frame offset from the caller; "padded+sizes": the blocks' frame counts are passed (no size exchange)
+        kw = dict(gather="records") if gather == "records" else dict(gather="padded")
+        if gather == "padded+sizes":
+            kw["frames_per_rank"] = [b - a for a, b in (shard_bounds(n_frames, world, r) for r in range(world))]
+        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), **kw)
         assert out["descriptors"].shape[0] == hi - lo and torch.equal(out["descriptors"], _extract(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), None)["descriptors"])
         # the boundary frames go first, as their own group, whenever the block is longer than the halo
         assert calls == ([spacing, hi - lo - spacing] if hi - lo > spacing else [hi - lo]), calls
         if rank == 0:
-            q.put((out["all_match_count"].numpy(), out["all_matches"].numpy(), out["all_quality"].numpy(), out["pairs_per_rank"],
-                   out["records"].numpy(), out["records_per_rank"]))
+            rec = (out["records"].numpy(), out["records_per_rank"]) if gather == "records" else (None, None)
+            assert ("records" in out) == (gather == "records")
+            q.put((out["all_match_count"].numpy(), out["all_matches"].numpy(), out["all_quality"].numpy(), out["pairs_per_rank"]) + rec)
         else:
             assert "all_matches" not in out and "records" not in out      # payload goes to rank 0 only
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,spacing,in_place", [(2, 9, 1, True), (3, 11, 2, True), (2, 4, 2, True), (4, 14, 1, True), (3, 10, 1, False)])
-def test_sharded_equals_single_process(world, n_frames, spacing, in_place):
+@pytest.mark.parametrize("world,n_frames,spacing,in_place,gather",
+                         [(2, 9, 1, True, "records"), (3, 11, 2, True, "padded+sizes"), (2, 4, 2, True, "padded"), (4, 14, 1, True, "padded+sizes"),
+                          (3, 10, 1, False, "records"), (3, 11, 2, True, "records"), (2, 9, 1, False, "padded")])
+def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gather):
     from sslam_amd.shard import shard_bounds
     # partition covers every frame exactly once, contiguously
     edges = [shard_bounds(n_frames, world, r) for r in range(world)]
@@ -115,7 +122,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing, in_place):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place, gather)) for r in range(world)]
     for p in procs:
         p.start()
     cnt, mt, qual, per_rank, records, rec_per_rank = q.get(timeout=120)
@@ -129,6 +136,8 @@ def test_sharded_equals_single_process(world, n_frames, spacing, in_place):
     assert np.array_equal(mt, ref["matches"].numpy())
     assert np.array_equal(qual.view(np.uint32), ref["quality"].numpy().view(np.uint32))
     assert cnt.sum() > 0
+    if gather != "records":
+        return          # padded form: the arrays above ARE what travelled, received in place
     # the wire format: one 16-byte record per match, pairs ascending, idx1 ascending inside a pair - nothing padded travels
     assert records.shape == (int(cnt.sum()), 4) and records.dtype == np.int32 and sum(rec_per_rank) == records.shape[0]
     assert np.array_equal(records[:, 0], np.repeat(np.arange(n_frames - spacing), cnt))
