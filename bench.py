@@ -195,6 +195,9 @@ def main():
                     "absent or not given: a synthetic directory of the workload's first frames is written to a temp dir")
     ap.add_argument("--tum-frames", type=int, default=128, help="frames of the directory leg (synthetic directory size / max_frames)")
     ap.add_argument("--no-directory", action="store_true", help="skip the directory -> matches leg")
+    ap.add_argument("--halo", choices=("late", "early"), default="late",
+                    help="N > 1: extract the block as one launch group and exchange the boundary frames afterwards (one small transfer "
+                         "exposed), or extract the boundary frames first as their own group (transfer hidden, +0.26 ms of small launches)")
     ap.add_argument("--gather", choices=("padded", "records"), default="padded",
                     help="N > 1: how the matches reach rank 0 - fixed-capacity arrays received in place (no device work, no host "
                          "synchronisation) or compacted 16-byte records (half the bytes, a size exchange and an expansion on rank 0)")
@@ -248,7 +251,8 @@ def main():
     # one sequence of n * world frames, cut into contiguous blocks (shard_bounds); this rank generates its own block
     lo, hi = shard_bounds(n * world, world, rank)
     imgs, toks = synth_sequence(n * world, lo, hi, h, w, grid, dev, seed=1234)
-    runner = ShardedSequenceRunner(pipe.extract, pipe.match, spacing=cfg.spacing)
+    runner = ShardedSequenceRunner(pipe.extract, pipe.match, spacing=cfg.spacing, alloc_fn=lambda rows: pipe.alloc_extract(rows, True),
+                                   halo=args.halo)
     ranges = [[lo, hi]]
     if world > 1:
         rg = [None] * world
@@ -600,7 +604,7 @@ def main():
         elif world > 1:
             res["parallelism_backend"] = "nccl (RCCL)"
         if world > 1:
-            res["gather"] = args.gather
+            res["gather"], res["halo"] = args.gather, args.halo
         if not ok and rehearse is None:
             # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
             res["value_unverified"], res["value"] = res["value"], None

@@ -7,9 +7,11 @@ statistics are per frame), so the only data that crosses GPUs is what the matche
 results:
 
   1. halo - each rank sends the descriptors / scores / intensities of its FIRST `spacing` frames to rank-1 (point to
-     point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link).  Those frames are extracted FIRST, as their
-     own small launch group, and the isend / irecv are posted before the rest of the block is extracted - the transfer
-     overlaps the bulk of the extraction;
+     point, <= 260 KB per frame at K = 500: latency-bound on one xGMI link).  Default ("late"): the block is extracted as one
+     launch group into buffers with `spacing` spare rows, then the exchange is posted and the matcher waits for it - one small
+     point-to-point transfer exposed per step.  "early": those frames are extracted FIRST, as their own small launch group,
+     and the isend / irecv are posted before the rest of the block is extracted - the transfer hides under the extraction, but
+     the one-frame extraction costs more than it hides (ShardedSequenceRunner.__init__);
   2. results - rank 0 alone receives the matches, in one of two forms (`ShardedSequenceRunner.run(gather=...)`):
      "padded" (default): every rank r > 0 sends its fixed-capacity match arrays as they are - (pairs, K, 2) int64, (pairs, K)
      fp32, (pairs,) int32 counts; 20 bytes per SLOT, 6.1 MB per 612 pairs at K = 500 - and rank 0 receives them IN PLACE into
@@ -178,8 +180,19 @@ class ShardedSequenceRunner:
     Pair numbers in the gathered records are the SEQUENCE's pair numbers: every rank sends local pair indices and rank 0
     adds the exclusive prefix sum of the ranks' pair counts (from the size exchange) - callers pass no offset."""
 
-    def __init__(self, extract_fn: Callable, match_fn: Callable, spacing: int = 1, group=None):
+    def __init__(self, extract_fn: Callable, match_fn: Callable, spacing: int = 1, group=None, alloc_fn: Callable | None = None,
+                 halo: str = "late"):
+        """alloc_fn(rows) -> dict of output buffers of extract_fn for `rows` frames (SequencePipeline.alloc_extract).
+        halo: "late" (needs alloc_fn and an extract_fn that takes `out`) - the block is extracted as ONE launch group into
+        buffers with `spacing` spare rows, then the first frames' fields go to rank - 1 and the neighbour's arrive in the
+        spare rows: what stays exposed is one small point-to-point exchange in front of the matcher;
+        "early" - the boundary frames are extracted first, as their own group, and travel while the rest of the block is
+        extracted: nothing exposed, but a one-frame extraction is a latency-bound pass of its own (tools/halo_cost.py:
+        +0.26 ms per 613-frame block, 2.4 % of the step - more than the exchange it hides).  Without alloc_fn: "early"."""
+        if halo not in ("late", "early"):
+            raise ValueError(f"halo must be 'late' or 'early', got {halo!r}")
         self.extract_fn, self.match_fn, self.spacing, self.group = extract_fn, match_fn, spacing, group
+        self.alloc_fn, self.halo = alloc_fn, halo
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
@@ -215,6 +228,15 @@ class ShardedSequenceRunner:
         if self.world == 1:
             ex = self.extract_fn(tokens_local, images_local)
             fields = {k: ex.get(k) for k in names}
+        elif self.halo == "late" and self.alloc_fn is not None and _takes_out(self.extract_fn):
+            # the whole block as ONE launch group, written into buffers with `sp` spare rows; then the exchange, then the matcher
+            n_halo = sp if self.rank < self.world - 1 else 0
+            full = self.alloc_fn(n + n_halo)
+            self.extract_fn(tokens_local, images_local, out={k: v[:n] for k, v in full.items()})
+            self._post_halo({k: (full[k][:sp] if k in full else None) for k in names},
+                            {k: full[k][n:n + sp] for k in names if k in full}).wait()
+            ex = {k: v[:n] for k, v in full.items()}
+            fields = {k: (full[k][:n + n_halo] if k in full else None) for k in names}
         else:
             # boundary frames first, as their own small launch group: their descriptors travel while the rest of the block
             # is being extracted.  Block buffers hold n rows + `sp` halo rows for the fields the matcher reads, so the

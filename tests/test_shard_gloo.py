@@ -60,7 +60,7 @@ def _pack(desc, sc, inten):
     return torch.from_numpy(np.concatenate([desc, sc[..., None], inten[..., None]], axis=-1))
 
 
-def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="records"):
+def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="records", halo="early"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -92,15 +92,24 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="reco
         def extract_plain(tokens, images):
             return extract(tokens, images)
 
-        runner = ShardedSequenceRunner(extract if in_place else extract_plain, _match, spacing=spacing)
+        K = desc.shape[1]
+
+        def alloc(rows):
+            return dict(descriptors=torch.empty((rows, K, 128)), scores=torch.empty((rows, K)), intensity=torch.empty((rows, K)))
+
+        runner = ShardedSequenceRunner(extract if in_place else extract_plain, _match, spacing=spacing,
+                                       alloc_fn=alloc if halo == "late" else None, halo=halo)
         # no frame offset from the caller; "padded+sizes": the blocks' frame counts are passed (no size exchange)
         kw = dict(gather="records") if gather == "records" else dict(gather="padded")
         if gather == "padded+sizes":
             kw["frames_per_rank"] = [b - a for a, b in (shard_bounds(n_frames, world, r) for r in range(world))]
         out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), **kw)
         assert out["descriptors"].shape[0] == hi - lo and torch.equal(out["descriptors"], _extract(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), None)["descriptors"])
-        # the boundary frames go first, as their own group, whenever the block is longer than the halo
-        assert calls == ([spacing, hi - lo - spacing] if hi - lo > spacing else [hi - lo]), calls
+        if halo == "late" and in_place:
+            assert calls == [hi - lo], calls           # the block is ONE launch group; the exchange follows it
+        else:
+            # the boundary frames go first, as their own group, whenever the block is longer than the halo
+            assert calls == ([spacing, hi - lo - spacing] if hi - lo > spacing else [hi - lo]), calls
         if rank == 0:
             rec = (out["records"].numpy(), out["records_per_rank"]) if gather == "records" else (None, None)
             assert ("records" in out) == (gather == "records")
@@ -111,10 +120,11 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="reco
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,spacing,in_place,gather",
-                         [(2, 9, 1, True, "records"), (3, 11, 2, True, "padded+sizes"), (2, 4, 2, True, "padded"), (4, 14, 1, True, "padded+sizes"),
-                          (3, 10, 1, False, "records"), (3, 11, 2, True, "records"), (2, 9, 1, False, "padded")])
-def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gather):
+@pytest.mark.parametrize("world,n_frames,spacing,in_place,gather,halo",
+                         [(2, 9, 1, True, "records", "early"), (3, 11, 2, True, "padded+sizes", "late"), (2, 4, 2, True, "padded", "late"),
+                          (4, 14, 1, True, "padded+sizes", "late"), (3, 10, 1, False, "records", "late"), (3, 11, 2, True, "records", "early"),
+                          (2, 9, 1, False, "padded", "early"), (4, 14, 1, True, "padded+sizes", "early")])
+def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gather, halo):
     from sslam_amd.shard import shard_bounds
     # partition covers every frame exactly once, contiguously
     edges = [shard_bounds(n_frames, world, r) for r in range(world)]
@@ -122,7 +132,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gathe
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place, gather)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place, gather, halo)) for r in range(world)]
     for p in procs:
         p.start()
     cnt, mt, qual, per_rank, records, rec_per_rank = q.get(timeout=120)
