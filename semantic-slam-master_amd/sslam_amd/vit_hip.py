@@ -3,8 +3,6 @@ module: packs its Parameters into device buffers (matrices bf16, vectors fp32), 
 workspace.  PyTorch is plumbing; no torch op takes part in the forward."""
 from __future__ import annotations
 
-import ctypes as C
-import os
 
 import torch
 

@@ -1,6 +1,6 @@
 """Times the bf16-mode kernels on synthetic tokens (613 frames): python tools/bench_bf16.py"""
-import os, sys, time
-import numpy as np, torch
+import os, sys
+import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "semantic-slam-master_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import synth

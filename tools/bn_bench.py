@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A2 (token BatchNorm, per-frame statistics) at the three BASELINE grids: time and algorithmic TB/s (tokens read once +
 features written once) of the register-resident forms against the three-sweep kernel.  python tools/bn_bench.py"""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A3 (exact conv) time per launch shape and frame count: where the latency forms stop paying.  python tools/conv_forms.py"""
 import os, sys, time
-import numpy as np, torch
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)

@@ -1,5 +1,5 @@
 """Library yardstick for the ViT-S/16 shapes (NOT used by the product): torch.matmul (hipBLASLt/rocBLAS) and SDPA in bf16."""
-import torch, time
+import torch
 def timeit(fn, n=20):
     for _ in range(5): fn()
     torch.cuda.synchronize()
