@@ -25,7 +25,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: 
 namespace {
 
 constexpr int VD = 384, VH = 6, VHD = 64, VMLP = 1536, VPATCH = 16, VPREFIX = 5, VLAYERS = 12;
-constexpr float LOG2E = 1.44269504088896341f;
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -592,7 +591,7 @@ struct EpiQKV {
 // ring shared by all eight waves: group g + 1 is in flight while group g is multiplied, one barrier per group.  The
 // epilogue is EpiResidual (x += out, LayerNorm partial sums of the new rows).
 constexpr int MF_GROUP_BYTES = 48 * 1024, MF_CHUNKS = VMLP / 64;
-constexpr int MF_XCH_BYTES = 8 * 2 * 1024;                                   // per wave: two 1 KB fragments
+static_assert(8 * 2 * 1024 <= 8 * RT_STG_BYTES, "the exchange tiles (two 1 KB fragments per wave) overlay the staging tiles");
 constexpr int MF_LDS_BYTES = 2 * MF_GROUP_BYTES + 8 * RT_STG_BYTES + 4 * (2 * VD + VMLP + VD);   // ring + staging (overlaid by the exchange) + vectors
 
 __device__ __forceinline__ void mf_dma_group(const bf16 *src, char *dst, int wave, int lane) {
