@@ -140,7 +140,7 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
     }
     __device__ __forceinline__ void load(bf16x8 (&a)[RT_KS], int row0, int kc, char *stg, const float *vec, int lane, int M) const {
         const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
-        float mean[4], rstd[4];
+        float mean[4], rstd[4], nmr[4];
         const float *xr[4];
         f32x4 st4[4];
 #pragma unroll
@@ -153,6 +153,7 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
             mean[i] = (st.x + st.z) * (1.0f / VD);
             const float var = fmaxf((st.y + st.w) * (1.0f / VD) - mean[i] * mean[i], 0.0f);
             rstd[i] = rsqrtf(var + eps);
+            nmr[i] = -mean[i] * rstd[i];
             xr[i] = x + (long long)row * VD + 4 * p;
         }
         // six batches of 64 features (8 x 16 bytes per lane each).  ALL 48 loads are requested up front - 192 registers, free at
@@ -175,8 +176,12 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                               \
             const f32x4 v = src[hf][i];                                                                               \
             uint2 o;                                                                                                  \
-            o.x = pack_bf16x2((v.x - mean[i]) * rstd[i] * gm.x + bt.x, (v.y - mean[i]) * rstd[i] * gm.y + bt.y);      \
-            o.y = pack_bf16x2((v.z - mean[i]) * rstd[i] * gm.z + bt.z, (v.w - mean[i]) * rstd[i] * gm.w + bt.w);      \
+            /* (v - mean) rstd gamma + beta as two fused multiply-adds per value (nmr = -mean rstd): half the vector */   \
+            /* instructions of the sub / mul / mul / add form - this prologue is a quarter of the QKV wave's instruction stream */ \
+            o.x = pack_bf16x2(__builtin_fmaf(__builtin_fmaf(v.x, rstd[i], nmr[i]), gm.x, bt.x),                       \
+                              __builtin_fmaf(__builtin_fmaf(v.y, rstd[i], nmr[i]), gm.y, bt.y));                      \
+            o.y = pack_bf16x2(__builtin_fmaf(__builtin_fmaf(v.z, rstd[i], nmr[i]), gm.z, bt.z),                       \
+                              __builtin_fmaf(__builtin_fmaf(v.w, rstd[i], nmr[i]), gm.w, bt.w));                      \
             *reinterpret_cast<uint2 *>(stg + (8 * i + q) * RT_STG_ROW + 64 * hf + 8 * p) = o;                         \
         }                                                                                                             \
     }                                                                                                                 \
