@@ -289,6 +289,36 @@ def chunk_bounds(n: int, chunk: int, first: int | None = None) -> list:
 
 
 @torch.no_grad()
+def spacing_summary(result: dict, spacing: int, max_pairs: int | None = None) -> dict:
+    """The statistics process_spacing prints for one spacing (visualize_matches_sequence.py:345-356), from a
+    StreamingSequence / run_directory / run_frames result: the reference visits the pairs (i, i + spacing) for
+    i = 0, spacing, 2 spacing, ... and stops after `max_pairs` of them (:297-299; CLI default 1, :371) - the result holds
+    EVERY pair (i, i + spacing), so the reference's subset is a strided slice of it.  One device-side reduction and one
+    host read-back of six numbers.  Returns {'pairs', 'matches', 'mean_quality', 'min_quality', 'max_quality',
+    'high_quality'} ('high_quality': matches with quality > 0.8; the three quality figures are None without matches, where the
+    reference prints no summary)."""
+    if spacing not in result:
+        return dict(pairs=0, matches=0, mean_quality=None, min_quality=None, max_quality=None, high_quality=0)
+    m = result[spacing]
+    n_pairs_all = m["match_count"].shape[0]
+    first = StreamingSequence.reference_pairs(n_pairs_all + spacing, spacing, max_pairs)
+    if not first:
+        return dict(pairs=0, matches=0, mean_quality=None, min_quality=None, max_quality=None, high_quality=0)
+    step = spacing
+    q = m["quality"][first[0]:first[-1] + 1:step]
+    cnt = m["match_count"][first[0]:first[-1] + 1:step].long()
+    valid = torch.arange(q.shape[1], device=q.device)[None, :] < cnt[:, None]
+    total = cnt.sum()
+    qs = torch.where(valid, q, torch.zeros((), dtype=q.dtype, device=q.device))
+    stats = torch.stack([total.double(), qs.double().sum(),
+                         torch.where(valid, q, torch.full((), float("inf"), dtype=q.dtype, device=q.device)).min().double(),
+                         torch.where(valid, q, torch.full((), float("-inf"), dtype=q.dtype, device=q.device)).max().double(),
+                         (valid & (q > 0.8)).sum().double()]).tolist()
+    tot = int(stats[0])
+    return dict(pairs=len(first), matches=tot, mean_quality=(stats[1] / tot if tot else None),
+                min_quality=(stats[2] if tot else None), max_quality=(stats[3] if tot else None), high_quality=int(stats[4]))
+
+
 def _push_vit_groups(pipe: SequencePipeline, seq: "StreamingSequence", feeder: "FrameFeeder", n: int, chunk: int,
                      group: int | None = None):
     """ViT-inside feed loop: the ViT runs chunk by chunk as the uploads arrive (its launch group, 82 frames at 448 x 448), but

@@ -311,3 +311,39 @@ def test_chunk_bounds_and_feeder_arguments():
     assert chunk_bounds(0, 8) == []
     with pytest.raises(ValueError):
         FrameFeeder(4, 2, 2, "cpu", [(0, 4)])                                   # neither fill nor pinned_source
+
+
+def test_spacing_summary_is_the_reference_loop_over_its_pair_subset():
+    """harness.spacing_summary == the statistics process_spacing accumulates (visualize_matches_sequence.py:294-356): pairs
+    (i, i + s) for i = 0, s, 2 s, ... up to max_pairs, all their match qualities pooled - restated here as the plain Python loop."""
+    import numpy as np
+    import torch
+    from sslam_amd.harness import spacing_summary
+    rng = np.random.default_rng(5)
+    n, K = 23, 40
+    res = {}
+    for s in (1, 5, 10):
+        p = n - s
+        cnt = rng.integers(0, K + 1, p).astype(np.int32)
+        cnt[::4] = 0
+        q = rng.random((p, K)).astype(np.float32)
+        q *= (np.arange(K)[None, :] < cnt[:, None])
+        res[s] = dict(quality=torch.from_numpy(q), match_count=torch.from_numpy(cnt), matches=torch.zeros((p, K, 2), dtype=torch.int64))
+    for s in (1, 5, 10):
+        for max_pairs in (None, 1, 3, 100):
+            pool, pairs = [], 0
+            for i in range(0, n - s, s):                              # the reference's loop
+                if max_pairs is not None and pairs >= max_pairs:
+                    break
+                c = int(res[s]["match_count"][i])
+                pool.extend(res[s]["quality"][i, :c].tolist())
+                pairs += 1
+            got = spacing_summary(res, s, max_pairs)
+            assert got["pairs"] == pairs and got["matches"] == len(pool)
+            if pool:
+                assert abs(got["mean_quality"] - float(np.mean(pool))) < 1e-6
+                assert got["min_quality"] == np.float32(min(pool)) and got["max_quality"] == np.float32(max(pool))
+                assert got["high_quality"] == sum(v > 0.8 for v in pool)
+            else:
+                assert got["mean_quality"] is None and got["high_quality"] == 0
+    assert spacing_summary(res, 20)["pairs"] == 0                     # a spacing the result does not hold
