@@ -161,6 +161,18 @@ def test_run_directory_equals_resident_run(T, pipe, tmp_path):
         for s in SPACINGS:
             _assert_same(T, got[s], want[s], ("matches", "quality", "match_count"))
         _assert_same(T, got[1], one, ("matches", "quality", "match_count"))
+    # the per-spacing statistics process_spacing prints (:345-356), on device tensors, against the oracle on the reference's pairs
+    from sslam_amd.harness import spacing_summary
+    fr = {k: v.cpu().numpy() for k, v in got["frames"].items()}          # (equal to the oracle's: checked frame by frame above)
+    for s, max_pairs in ((5, 2), (10, None)):
+        pool = []
+        first = StreamingSequence.reference_pairs(n, s, max_pairs)
+        for i in first:
+            pool.extend(_oracle_pair(fr, i, i + s)[1].tolist())
+        sm = spacing_summary(got, s, max_pairs)
+        assert sm["pairs"] == len(first) and sm["matches"] == len(pool) and sm["high_quality"] == sum(v > 0.8 for v in pool)
+        if pool:
+            assert abs(sm["mean_quality"] - float(np.mean(pool))) < 1e-6 and sm["max_quality"] == np.float32(max(pool))
     # host-resident frames (pinned, uploaded straight from the array; and pageable through the staging buffers)
     pinned = T.from_numpy(imgs_h).pin_memory()
     got = run_frames(pipe, n, 480, 640, spacings=(1,), tokens=toks, pinned_source=pinned, chunk=6, first_chunk=2)
