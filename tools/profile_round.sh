@@ -56,6 +56,8 @@ echo "[8] round-3 additions: A2 at the three grids, host -> device feed (sweep +
 python $ROOT/tools/bn_bench.py > $OUT/${TAG}_bn_grids.txt 2>/dev/null
 python $ROOT/tools/m1_bench.py > $OUT/${TAG}_m1_shapes.txt 2>/dev/null
 python $ROOT/tools/refine_bench.py > $OUT/${TAG}_refine_entries.txt 2>/dev/null
+python $ROOT/tools/gather_cost.py > $OUT/${TAG}_multi_rank_costs.txt 2>/dev/null
+python $ROOT/tools/halo_cost.py >> $OUT/${TAG}_multi_rank_costs.txt 2>/dev/null
 python $ROOT/tools/upload_sweep.py > $OUT/${TAG}_upload_sweep.txt 2>/dev/null
 python $ROOT/tools/upload_timeline.py 307 > $OUT/${TAG}_upload_timeline.txt 2>/dev/null
 for wl in fr1_xyz_50 fr2_desk_1024kp synthetic_2048kp; do
