@@ -12,6 +12,8 @@ for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROO
     sys.path.insert(0, p)
 import synth
 from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (the probe build)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
 L = lib.lib()
 if not hasattr(L, "sslam_probe_refine"):
