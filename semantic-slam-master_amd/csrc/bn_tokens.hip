@@ -141,9 +141,14 @@ __global__ __launch_bounds__(256) void bn_tokens_kernel(const float *__restrict_
 template <int V>
 struct VecT;
 template <>
-struct VecT<4> { typedef float4 T; };
+struct VecT<4> { typedef float4 T; typedef float N __attribute__((ext_vector_type(4))); };
 template <>
-struct VecT<2> { typedef float2 T; };
+struct VecT<2> { typedef float2 T; typedef float N __attribute__((ext_vector_type(2))); };
+// the tokens are read exactly once: non-temporal loads keep them from displacing the lines other kernels' operands live in
+template <int V>
+__device__ __forceinline__ typename VecT<V>::T load_once(const float *p) {
+    return __builtin_bit_cast(typename VecT<V>::T, __builtin_nontemporal_load(reinterpret_cast<const typename VecT<V>::N *>(p)));
+}
 
 template <int V>
 __device__ __forceinline__ void comb16v(const float (&v)[V], float (&t)[V], float (*sh)[64], int wave, int lane) {
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, WPS) void bn_tokens_reg_kernel(const float *__
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             t[i] = vec{};
-            if (valid(NR + i)) t[i] = *reinterpret_cast<const vec *>(src + (size_t)(NR + i) * 16 * SSLAM_C + loff);
+            if (valid(NR + i)) t[i] = load_once<V>(src + (size_t)(NR + i) * 16 * SSLAM_C + loff);
         }
 #pragma unroll
         for (int i = 0; i < NL; i++) hold[i][tid] = t[i];      // own slots only: no barrier between these stores and the loads below
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, WPS) void bn_tokens_reg_kernel(const float *__
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         vec v = {};
-        if (valid(i)) v = *reinterpret_cast<const vec *>(src + (size_t)i * 16 * SSLAM_C + loff);
+        if (valid(i)) v = load_once<V>(src + (size_t)i * 16 * SSLAM_C + loff);
 #pragma unroll
         for (int j = 0; j < V; j++) x[i][j] = reinterpret_cast<const float *>(&v)[j];
     }
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, WPS) void bn_tokens_reg_kernel(const float *__
         float y[V];
 #pragma unroll
         for (int j = 0; j < V; j++) y[j] = xv[j] * al[j] + bs[j];
-        *reinterpret_cast<vec *>(dst + (size_t)i * 16 * SSLAM_C + loff) = *reinterpret_cast<const vec *>(y);
+        __builtin_nontemporal_store(*reinterpret_cast<const typename VecT<V>::N *>(y), reinterpret_cast<typename VecT<V>::N *>(dst + (size_t)i * 16 * SSLAM_C + loff));
         if (dst_bf) {   // bf16 copy for the throughput-mode saliency CNN (selector_bf16.hip)
             unsigned o[V / 2];
 #pragma unroll

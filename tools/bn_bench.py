@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (experiments)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 
 dev = "cuda"
 ones, zeros = torch.ones(384, device=dev), torch.zeros(384, device=dev)
