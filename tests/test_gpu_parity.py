@@ -388,6 +388,58 @@ def test_end_to_end_golden(T, hip):
     assert hip.launch_count() > 0
 
 
+@pytest.mark.parametrize("tag", ["e2e_g40", "e2e_g60"])
+def test_end_to_end_golden_larger_grids(T, hip, tag):
+    """BASELINE configs[2] / configs[4] shapes against the reference's own chain (8 frames at G = 40 / K = 1024, 16 at G = 60 /
+    K = 2048; tests/golden/make_golden_e2e_grids.py): keypoint sets, order up to near-tie swaps, scores / descriptors /
+    intensities by cell, match pairs as indices where both frames are index-exact and as (cell, cell) pairs always - the bars
+    of tests/e2e_check.py, the same the CPU oracle is held to - and the HIP path equal to the oracle bit for bit."""
+    import e2e_check
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    g = e2e_check.gold(tag)
+    grid, K, n = int(g["grid"]), int(g["K"]), int(g["n_frames"])
+    toks = synth.token_sequence(n, grid)
+    imgs = synth.image_sequence(n, int(g["height"]), int(g["width"]))
+    pipe = SequencePipeline(ExtractorConfig(input_size=16 * grid, num_keypoints=K), synth.selector_state(0), synth.refiner_state(0))
+    ex = pipe.extract(dev(T, toks), dev(T, imgs))
+    idx, sc = ex["idx"].cpu().numpy(), ex["scores"].cpu().numpy()
+    desc, inten = ex["descriptors"].cpu().numpy(), ex["intensity"].cpu().numpy()
+    assert not ex["status"].cpu().numpy().any()
+
+    def match(a, b):
+        sel = T.tensor([a, b], device="cuda")
+        m = pipe.match(ex["descriptors"][sel], ex["scores"][sel], ex["intensity"][sel], spacing=1)
+        c = int(m["match_count"].cpu()[0])
+        return m["matches"].cpu().numpy()[0, :c], m["quality"].cpu().numpy()[0, :c]
+    rep = e2e_check.check_sequence(tag, idx, sc, desc, inten, match)
+    assert len(rep["pairs"]) >= 8
+    # and the same frames through the oracle: bit-identical (so the order report of the CPU suite is the GPU's too)
+    feat = ora.bn_tokens(toks)[0].reshape(n, grid, grid, 384)
+    okp, osc, oidx, _ = ora.select_keypoints(ora.selector_saliency(feat, synth.selector_state(0)), K)
+    assert np.array_equal(idx, oidx)
+    assert_bits(sc, osc, "scores")
+    assert_bits(desc, ora.refine(ora.gather(feat, okp), synth.refiner_state(0)), "descriptors")
+    # all spacing-1 pairs in ONE batched launch equal the per-pair calls above
+    m = pipe.match(ex["descriptors"], ex["scores"], ex["intensity"], spacing=1)
+    for p in range(n - 1):
+        c = int(m["match_count"].cpu()[p])
+        want = g[f"pair_{p}_{p + 1}_matches"].astype(np.int64)
+        got_c = e2e_check.cell_pairs(m["matches"].cpu().numpy()[p, :c], idx[p], idx[p + 1])
+        want_c = e2e_check.cell_pairs(want, g[f"f{p}_idx"], g[f"f{p + 1}_idx"])
+        assert np.array_equal(got_c[np.lexsort(got_c.T[::-1])], want_c[np.lexsort(want_c.T[::-1])]), (tag, p)
+
+
+def test_bn_tokens_batch_of_four_golden(T, hip):
+    """B = 4 as train.py:300-302 calls the backbone: one set of statistics over 4 x 784 tokens (reference output)."""
+    g = gold("bn_tokens_b4")
+    tok = synth.tokens(int(g["frame"]), 28, batch=4)
+    ones, zeros = dev(T, np.ones(384, np.float32)), dev(T, np.zeros(384, np.float32))
+    for train, key in [(True, "train_b4_sub"), (False, "eval_b4_sub")]:
+        y, _, _ = hip.bn_tokens(dev(T, tok), 5, 4, ones, zeros, zeros, ones, train, 1e-5)
+        assert_bits(y.cpu().numpy(), ora.bn_tokens(tok, group=4, train=train)[0], "bn group of 4")
+        assert np.abs(y.cpu().numpy()[:, ::int(g["sub_step"])] - g[key]).max() < 5e-6
+
+
 # ------------------------------------------------------------------------- the matcher module (M1..M5 signatures)
 def test_matching_module_m1_to_m5(T, hip):
     import matching

@@ -50,6 +50,20 @@ def test_bn_tokens_train_and_eval():
     assert np.abs(rv2 - g["train_b2_running_var"]).max() < 1e-5
 
 
+def test_bn_tokens_batch_of_four():
+    """train.py:300-302 runs the backbone on B = 4: statistics over 4 x 784 tokens (bn_tokens_b4.npz, reference output)."""
+    g = gold("bn_tokens_b4")
+    tok = synth.tokens(int(g["frame"]), 28, batch=4)
+    step = int(g["sub_step"])
+    y, mean, var = ora.bn_tokens(tok, group=4, train=True)
+    assert np.abs(y[:, ::step] - g["train_b4_sub"]).max() < 5e-6
+    assert np.abs(y.astype(np.float64).sum(axis=1) - g["train_b4_sum64"]).max() < 1e-3
+    assert np.abs(0.1 * mean[0] - g["train_b4_running_mean"]).max() < 1e-6
+    assert np.abs(0.9 + 0.1 * var[0] * (3136.0 / 3135.0) - g["train_b4_running_var"]).max() < 1e-5
+    ye, _, _ = ora.bn_tokens(tok, group=4, train=False)
+    assert np.array_equal(ye[:, ::step], g["eval_b4_sub"])
+
+
 # ------------------------------------------------------------------------------------------- A3 / A4 / A5
 @pytest.fixture(scope="module")
 def sel_feats():
@@ -282,6 +296,60 @@ def test_end_to_end_three_frames():
         assert np.array_equal(mt, g[f"pair{a}{b}_matches"])                   # match pairs: exact
         assert np.abs(q - g[f"pair{a}{b}_quality"]).max() < 1e-5
         assert len(mt) > 100
+
+
+def _oracle_sequence(tag):
+    import e2e_check
+    g = e2e_check.gold(tag)
+    grid, K, n = int(g["grid"]), int(g["K"]), int(g["n_frames"])
+    toks = synth.token_sequence(n, grid)
+    imgs = synth.image_sequence(n, int(g["height"]), int(g["width"]))
+    feat = ora.bn_tokens(toks)[0].reshape(n, grid, grid, 384)
+    sal = ora.selector_saliency(feat, synth.selector_state(0))
+    kp, sc, idx, st = ora.select_keypoints(sal, K)
+    assert not st.any()
+    desc = ora.refine(ora.gather(feat, kp), synth.refiner_state(0))
+    inten = np.stack([ora.intensity(imgs[i], 16 * grid, ora.patch_to_pixel(kp[i])) for i in range(n)])
+
+    def match(a, b):
+        return ora.match_with_quality(desc[a], desc[b], sc[a], sc[b], intensity1=inten[a], intensity2=inten[b],
+                                      **e2e_check.CLI)
+    return e2e_check.check_sequence(tag, idx, sc, desc, inten, match), sal
+
+
+@pytest.mark.parametrize("tag", ["e2e_g40", "e2e_g60"])
+def test_end_to_end_larger_grids(tag):
+    """8 frames at G = 40 / K = 1024 (configs[2]) and 16 at G = 60 / K = 2048 (configs[4]) through the reference's whole chain
+    (tests/golden/make_golden_e2e_grids.py) against the oracle; bars in tests/e2e_check.py.  On the reference's own saliency
+    BITS the selection is index-exact wherever that map has no exactly equal values (torch.topk leaves those unordered)."""
+    import e2e_check
+    rep, sal = _oracle_sequence(tag)
+    g = e2e_check.gold(tag)
+    K = int(g["K"])
+    for i, f in enumerate(rep["frames"]):
+        assert np.abs(sal[i] - g[f"f{i}_sal"]).max() < 5e-6
+        if f["ref_exact_ties"] == 0:
+            _, _, idx, _ = ora.select_keypoints(g[f"f{i}_sal"], K)
+            assert np.array_equal(idx[0], g[f"f{i}_idx"].astype(np.int32)), (tag, i)
+    s = e2e_check.summarise(rep["frames"])
+    if tag == "e2e_g40":
+        assert s["swapped_positions_max"] <= 2 and s["index_exact_frames"] >= 7, s
+        assert all(p["index_exact"] for p in rep["pairs"])
+    assert all(p["cells_equal"] for p in rep["pairs"]) and len(rep["pairs"]) >= 8
+
+
+def test_keypoint_order_rate_g60():
+    """The measured size of the one caveat of the parity claim: over 32 + 16 frames at G = 60 / K = 2048, how often the
+    oracle's keypoint ORDER differs from torch's (the set never does).  tools/order_swap_rate.py prints the table quoted in
+    DESIGN.md; here the rate is bounded so that a regression of the canonical order shows."""
+    import e2e_check
+
+    def idx_of(i, seed):
+        feat = ora.bn_tokens(synth.tokens(seed, 60))[0].reshape(1, 60, 60, 384)
+        return ora.select_keypoints(ora.selector_saliency(feat, synth.selector_state(0)), 2048)[2][0]
+    frames = e2e_check.check_order_set(idx_of)
+    s = e2e_check.summarise(frames)
+    assert s["frames"] == 32 and s["swapped_positions_mean"] < 8 and s["max_gap"] <= e2e_check.NEAR_TIE, s
 
 
 def test_canonical_exp_accuracy():
