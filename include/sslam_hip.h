@@ -195,7 +195,10 @@ int sslam_keypoint_intensity(const uint8_t *img, int n, int h, int w, int size, 
  * sslam_sim_argmax_ws, batched calls (n_pairs >= 16) with workspace_bytes >= sslam_sim_argmax_workspace_bytes(n2, n_pairs)
  * = n_pairs*n2*8 bytes of caller-owned scratch: the similarity matrix is evaluated once and the column direction reduced
  * with 64-bit (value, ~index) keys and atomic max - deterministic.  Smaller calls, a NULL / short workspace, and the entry
- * without a workspace evaluate it once per direction and need no scratch.  Same bits either way. */
+ * without a workspace evaluate it once per direction and need no scratch.  Same bits either way.
+ * Precondition: finite descriptors (the refiner's L2-normalised rows are).  With NaN / Inf in the inputs the VALUES and the
+ * choice among candidates are unspecified (torch.argmax would return the first NaN), but every index written stays inside
+ * [0, n2) resp. [0, n1), so sslam_match_finalize and the sibling matchers never index out of range. */
 int sslam_sim_argmax(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2, int n2,
                      int n_pairs, int32_t *nn12, float *s12, int32_t *nn21, float *s21, float *second12, void *stream);
 int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1, const float *desc2, long long stride2, int n2,

@@ -8,6 +8,7 @@ long long g_sslam_launches = 0;
 long long g_sslam_knob[KNOB_COUNT];
 
 namespace {
+long long g_knob_at_load[KNOB_COUNT];   // what the environment said when the library was loaded: "unset" restores THIS
 const char *const kKnobNames[KNOB_COUNT] = {
     "SSLAM_M1_VARIANT",   "SSLAM_CONV_VARIANT",  "SSLAM_CONV_LATENCY_ROWS", "SSLAM_CONV_LAT2_ROWS",   "SSLAM_CONV_NO_HALO",
     "SSLAM_CONV_TAIL",    "SSLAM_CONVBF_NO_HALO", "SSLAM_CONVBF_TAIL",      "SSLAM_CONVBF_VARIANT",   "SSLAM_VIT_NO_FUSED_MLP",
@@ -17,7 +18,7 @@ struct KnobInit {
     KnobInit() {
         for (int i = 0; i < KNOB_COUNT; i++) {
             const char *e = getenv(kKnobNames[i]);
-            g_sslam_knob[i] = e ? atoll(e) : SSLAM_KNOB_UNSET;
+            g_sslam_knob[i] = g_knob_at_load[i] = e ? atoll(e) : SSLAM_KNOB_UNSET;
         }
     }
 } g_knob_init;
@@ -41,7 +42,9 @@ extern "C" int sslam_test_set_knob(const char *name, long long value, int unset)
     if (!name) return SSLAM_E_INVALID;
     for (int i = 0; i < KNOB_COUNT; i++)
         if (!strcmp(name, kKnobNames[i])) {
-            g_sslam_knob[i] = unset ? SSLAM_KNOB_UNSET : value;
+            // unset: back to the load-time value (an SSLAM_* variable exported for a whole test session survives the tests
+            // that flip the same knob), not to the built-in default
+            g_sslam_knob[i] = unset ? g_knob_at_load[i] : value;
             return SSLAM_OK;
         }
     return SSLAM_E_INVALID;

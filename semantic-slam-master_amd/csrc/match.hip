@@ -287,20 +287,25 @@ __global__ __launch_bounds__(NTM, 2) void sim_argmax_kernel(const float *__restr
         }
     }
     if (h == 0 && qok) {
-        o_idx[qi] = besti;
+        // finite descriptors always leave a candidate index here; a row of NaN similarities (non-finite input: results
+        // undefined, see sslam_hip.h) never beats -inf and would leave the initial 0x7fffffff - kept in range for the callers
+        o_idx[qi] = (unsigned)besti < (unsigned)nc ? besti : 0;
         if (o_val) o_val[qi] = best;
         if (o_sec) o_sec[qi] = second;
     }
 }
 
-__global__ __launch_bounds__(256) void keys_decode_kernel(const unsigned long long *__restrict__ keys, long long n,
+__global__ __launch_bounds__(256) void keys_decode_kernel(const unsigned long long *__restrict__ keys, long long n, int n1,
                                                            int *__restrict__ nn21, float *__restrict__ s21) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long kk = keys[i];
     unsigned u = (unsigned)(kk >> 32);
     u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
-    nn21[i] = (int)(~(unsigned)kk);
+    // with finite similarities a lane that holds a query always wins (a lane beyond the last query contributes the key of
+    // -inf with an index >= n1); NaN / Inf descriptors can let such a key, or the zero fill, win: keep the index in range
+    const unsigned qi = ~(unsigned)kk;
+    nn21[i] = qi < (unsigned)n1 ? (int)qi : 0;
     if (s21) s21[i] = __uint_as_float(u);
 }
 
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const int *__restri
         float sim = 0.f, avg = 0.f;
         if (i < n1) {
             j = nn12[i];
-            if (nn21[j] == i) {                                               // :149
+            if ((unsigned)j < (unsigned)n2 && nn21[j] == i) {                 // :149 (the range check: arrays not from sslam_sim_argmax)
                 sim = s12[i];
                 avg = (sc1[i] + sc2[j]) / 2.0f;                               // :163
                 ok = (avg >= t_sal) && (sim >= t_sim);                        // :166-168
@@ -407,7 +412,7 @@ extern "C" int sslam_sim_argmax_ws(const float *desc1, long long stride1, int n1
                                nn21, s21, second12, keys, n_pairs, qb1);
         SSLAM_CHECK_LAUNCH();
         const long long n = (long long)n_pairs * n2;
-        hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, nn21, s21);
+        hipLaunchKernelGGL(keys_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, n1, nn21, s21);
         SSLAM_CHECK_LAUNCH();
         return SSLAM_OK;
     }

@@ -205,14 +205,19 @@ class FrameFeeder:
             pbuf = FrameFeeder._cache.get(pkey)
             if pbuf is None or pbuf.numel() < pn:
                 pbuf = FrameFeeder._cache[pkey] = torch.empty(pn, dtype=torch.uint8).pin_memory()
-            self.pin = [pbuf[i * (pn // 2):(i + 1) * (pn // 2)].view(cmax, h, w, 3) for i in range(2)]
+                FrameFeeder._cache[(str(self.device), "staged")] = {}
+            # the two halves of THIS feeder may overlap either half of an earlier feeder's split of the same pinned buffer
+            # (other chunk size): the events of the last uploads FROM the buffer live beside it, keyed by byte range, and a
+            # half is written only after every recorded upload from an overlapping range has completed
+            self.pin_range = [(i * (pn // 2), (i + 1) * (pn // 2)) for i in range(2)]
+            self.pin = [pbuf[a:b].view(cmax, h, w, 3) for a, b in self.pin_range]
+            self._staged_events = FrameFeeder._cache.setdefault((str(self.device), "staged"), {})
         skey = (str(self.device), "stream")
         if skey not in FrameFeeder._cache:
             FrameFeeder._cache[skey] = torch.cuda.Stream(self.device)
         self.copy_stream = FrameFeeder._cache[skey]
         self.uploaded = [None] * nb                  # event per chunk: its H2D is complete (the compute waits on it)
         self.released = [None] * self.n_slots        # ring mode: the compute has finished with the slot (the copy waits on it)
-        self.staged = [None, None]                   # event per staging buffer: the last upload FROM it is complete
 
     def _view(self, i: int):
         a, b = self.bounds[i]
@@ -236,10 +241,14 @@ class FrameFeeder:
         completed - PIL decode and numpy copies release the GIL), then enqueue its upload."""
         a, b = self.bounds[i]
         ps = i & 1
-        if self.staged[ps] is not None:
-            self.staged[ps].synchronize()
+        lo, hi = self.pin_range[ps]
+        for (ea, eb), ev in list(self._staged_events.items()):
+            if ea < hi and lo < eb:                  # an upload FROM overlapping pinned bytes (this feeder's or an earlier one's)
+                ev.synchronize()
+                if lo <= ea and eb <= hi:
+                    self._staged_events.pop((ea, eb), None)
         self.fill(self.pin[ps][: b - a].numpy(), a, b)
-        self.staged[ps] = self._enqueue_upload(i, self.pin[ps][: b - a])
+        self._staged_events[(lo, hi)] = self._enqueue_upload(i, self.pin[ps][: b - a])
         return i
 
     def __iter__(self):

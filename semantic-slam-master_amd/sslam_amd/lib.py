@@ -186,7 +186,7 @@ def _scratch(workspace, need: int, device):
 
 class knobs:
     """TEST-ONLY: `with lib.knobs(SSLAM_CONV_TAIL=4): ...` overrides load-time knobs of the library for the block
-    (sslam_test_set_knob) and restores the defaults afterwards.  Product code never uses it."""
+    (sslam_test_set_knob) and restores their load-time values (environment at load, else the built-in defaults) afterwards.  Product code never uses it."""
 
     def __init__(self, **kv):
         self.kv = kv

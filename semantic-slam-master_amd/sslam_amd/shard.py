@@ -232,6 +232,10 @@ class ShardedSequenceRunner:
             # the whole block as ONE launch group, written into buffers with `sp` spare rows; then the exchange, then the matcher
             n_halo = sp if self.rank < self.world - 1 else 0
             full = self.alloc_fn(n + n_halo)
+            if images_local is None:
+                # alloc_fn does not know whether pixels were passed: without them nothing writes 'intensity' - it must not be
+                # exchanged or handed to the matcher (whose intensity threshold would then read uninitialised memory)
+                full = {k: v for k, v in full.items() if k != "intensity"}
             self.extract_fn(tokens_local, images_local, out={k: v[:n] for k, v in full.items()})
             self._post_halo({k: (full[k][:sp] if k in full else None) for k in names},
                             {k: full[k][n:n + sp] for k in names if k in full}).wait()

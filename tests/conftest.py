@@ -18,7 +18,8 @@ import pytest
 @pytest.fixture
 def knob():
     """Set a TEST-ONLY load-time knob of libsslam_hip.so for one test (sslam_test_set_knob; the library reads the
-    environment once at load, never per call) and restore the built-in default afterwards."""
+    environment once at load, never per call) and restore its load-time value afterwards (what the environment said when the
+    library was loaded, else the built-in default)."""
     from sslam_amd import lib
     touched = []
 

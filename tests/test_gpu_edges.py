@@ -88,3 +88,44 @@ def test_identical_frames_match_themselves(T, pipe):
         # a keypoint's best partner is the FIRST keypoint with its descriptor: itself unless an earlier duplicate exists
         assert np.all(m[:, 1] <= m[:, 0])
         assert T.equal(out["matches"][p], out["matches"][0]) and T.equal(out["quality"][p], out["quality"][0])
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_non_finite_descriptors_keep_indices_in_range(T, variant, knob):
+    """NaN / Inf descriptors are outside the matcher's contract (include/sslam_hip.h: values and the choice among candidates
+    unspecified) but must never produce an index outside the arrays: the finalise kernel and the sibling matchers index with
+    nn12 / nn21.  Both launch forms, ragged sizes (lanes beyond the last query contribute the key of -inf), whole rows NaN,
+    a non-finite ROW 0 (the row those lanes re-read), +-Inf entries; the finite pairs of the same launch stay bit-exact."""
+    from sslam_amd import lib
+    knob("SSLAM_M1_VARIANT", variant)
+    n, m, pairs = 77, 131, 17
+    d1 = np.stack([synth.unit_descriptors(800 + p, n, 128) for p in range(pairs)])
+    d2 = np.stack([synth.unit_descriptors(900 + p, m, 128) for p in range(pairs)])
+    d1[0, 5] = np.nan                      # one NaN row
+    d2[1, 0] = np.nan                      # row 0 of the candidate side
+    d1[2, 0] = np.inf                      # row 0 of the query side: what lanes beyond nq re-read
+    d1[3] = np.nan                         # everything NaN
+    d2[4, 7, 3] = -np.inf
+    d1[5, :, 0] = np.where(np.arange(n) % 2, np.nan, d1[5, :, 0])
+    d2[5, :, 1] = -np.nan
+    D1, D2 = T.from_numpy(d1).cuda(), T.from_numpy(d2).cuda()
+    ws = T.empty(max(8, lib.workspace_bytes(1, 28, max(n, m), pairs)), dtype=T.uint8, device="cuda")
+    nn12, s12, nn21, s21, _ = lib.sim_argmax(D1, n * 128, n, D2, m * 128, m, pairs, want_s21=True, workspace=ws)
+    a, b = nn12.cpu().numpy(), nn21.cpu().numpy()
+    assert a.min() >= 0 and a.max() < m and b.min() >= 0 and b.max() < n
+    sc1, sc2 = T.rand((pairs, n), device="cuda"), T.rand((pairs, m), device="cuda")
+    mt, q, cnt = lib.match_finalize(nn12, s12, nn21, n, m, pairs, sc1, n, sc2, m, None, None, 0.7, 0.3, 0.0, -1.0, 0.0)
+    T.cuda.synchronize()
+    mtc = mt.cpu().numpy()
+    assert mtc[..., 0].max() < n and mtc[..., 1].max() < m and mtc.min() >= 0
+    for p in range(6, pairs):              # untouched pairs: the oracle's bits
+        o12, os12, o21, os21 = ora.sim_argmax(d1[p], d2[p])
+        assert np.array_equal(a[p], o12) and np.array_equal(b[p], o21)
+        assert np.array_equal(s12.cpu().numpy()[p].view(np.uint32), os12.view(np.uint32))
+        assert np.array_equal(s21.cpu().numpy()[p].view(np.uint32), os21.view(np.uint32))
+    # arrays that did not come from sslam_sim_argmax: an out-of-range nn12 entry is skipped, not dereferenced
+    bad = nn12.clone()
+    bad[6, :4] = T.tensor([m, 1 << 30, -1, -(1 << 31)], dtype=bad.dtype, device="cuda")
+    mt2, _, cnt2 = lib.match_finalize(bad, s12, nn21, n, m, pairs, sc1, n, sc2, m, None, None, 0.7, 0.3, 0.0, -1.0, 0.0)
+    T.cuda.synchronize()
+    assert int(cnt2[6]) <= int(cnt[6]) and T.equal(cnt2[7:], cnt[7:])

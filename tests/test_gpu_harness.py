@@ -190,6 +190,31 @@ def test_run_directory_equals_resident_run(T, pipe, tmp_path):
         _assert_same(T, got["frames"], one, ("idx", "descriptors", "intensity"))
 
 
+def test_back_to_back_feeds_share_the_staging_buffer_safely(T, pipe):
+    """Two run_frames(fill=...) calls on the same device with NO host synchronisation between them: the pinned staging buffer
+    is cached per device, so the second feeder must not overwrite halves whose last uploads (the first sequence's last chunks)
+    are still in flight - the upload events live beside the buffer, not in the feeder instance.  Whole-buffer and ring mode,
+    different chunk sizes (the halves of the two feeders overlap differently), results bit-equal to the resident passes."""
+    from sslam_amd.harness import run_frames
+    n = 21
+    toks_h, imgs_h = synth.token_sequence(n, 28), synth.image_sequence(n)
+    imgs_r = np.ascontiguousarray(imgs_h[::-1])
+    toks, toks_r = T.from_numpy(toks_h).cuda(), T.from_numpy(np.ascontiguousarray(toks_h[::-1])).cuda()
+    one = {k: v.clone() for k, v in pipe.run(T.from_numpy(imgs_h).cuda(), toks).items()}
+    rev = {k: v.clone() for k, v in pipe.run(T.from_numpy(imgs_r).cuda(), toks_r).items()}
+    T.cuda.synchronize()
+    for kw in (dict(max_bytes=0, ring=2), dict()):
+        a = run_frames(pipe, n, 480, 640, spacings=(1,), tokens=toks, chunk=8, fill=lambda dst, lo, hi: np.copyto(dst, imgs_h[lo:hi]),
+                       feeder_kw=dict(kw))
+        b = run_frames(pipe, n, 480, 640, spacings=(1,), tokens=toks_r, chunk=5, fill=lambda dst, lo, hi: np.copyto(dst, imgs_r[lo:hi]),
+                       feeder_kw=dict(kw))
+        c = run_frames(pipe, n, 480, 640, spacings=(1,), tokens=toks, chunk=8, fill=lambda dst, lo, hi: np.copyto(dst, imgs_h[lo:hi]),
+                       feeder_kw=dict(kw))
+        for got, want in ((a, one), (b, rev), (c, one)):
+            _assert_same(T, got[1], want, ("matches", "quality", "match_count"))
+            _assert_same(T, got["frames"], want, ("idx", "descriptors", "intensity"))
+
+
 def test_run_directory_with_the_hip_vit(T, tmp_path):
     """images on disk -> A0 -> HIP ViT (A1) -> A2 .. M1: equal to the resident pass over the same launch groups."""
     from sslam_amd.harness import run_directory

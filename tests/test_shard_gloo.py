@@ -1,5 +1,5 @@
 """CPU test of the frame-sharded N > 1 path (sslam_amd/shard.py) with torch.distributed on the gloo backend,
-world_size 2, 3 and 4: block partition, early halo exchange of boundary-frame descriptors (boundary frames extracted as
+world_size 2, 3, 4 and 8: block partition, early halo exchange of boundary-frame descriptors (boundary frames extracted as
 their own launch group), gather of COMPACTED match records to rank 0 only.
 The compute functions are injected (here: the CPU oracle on small inputs; in production the HIP pipeline), so the
 test checks exactly the distributed logic: the sharded result must equal the single-process result pair for pair."""
@@ -34,10 +34,13 @@ def _make_inputs(n_frames, K=96, d=128):
 
 
 def _extract(tokens, images):
-    # "tokens" carries (desc | scores | intensity) packed per frame: extraction itself is not under test here
-    K = 96
+    # "tokens" carries (desc | scores | intensity) packed per frame: extraction itself is not under test here.
+    # Like SequencePipeline.extract, the intensity exists only when pixels were passed.
     t = tokens
-    return dict(descriptors=t[:, :, :128].contiguous(), scores=t[:, :, 128].contiguous(), intensity=t[:, :, 129].contiguous())
+    ex = dict(descriptors=t[:, :, :128].contiguous(), scores=t[:, :, 128].contiguous())
+    if images is not None:
+        ex["intensity"] = t[:, :, 129].contiguous()
+    return ex
 
 
 def _match(desc, sc, inten, sp):
@@ -49,7 +52,7 @@ def _match(desc, sc, inten, sp):
     cnt = torch.zeros((max(p, 0),), dtype=torch.int32)
     for i in range(p):
         m, qq = ora.match_with_quality(desc[i].numpy(), desc[i + sp].numpy(), sc[i].numpy(), sc[i + sp].numpy(), 0.3, 0.3, 0.5,
-                                       inten[i].numpy(), inten[i + sp].numpy(), 0.1)
+                                       None if inten is None else inten[i].numpy(), None if inten is None else inten[i + sp].numpy(), 0.1)
         mt[i, :len(m)] = torch.from_numpy(m)
         q[i, :len(m)] = torch.from_numpy(qq)
         cnt[i] = len(m)
@@ -60,7 +63,7 @@ def _pack(desc, sc, inten):
     return torch.from_numpy(np.concatenate([desc, sc[..., None], inten[..., None]], axis=-1))
 
 
-def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="records", halo="early"):
+def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="records", halo="early", with_images=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -95,7 +98,9 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="reco
         K = desc.shape[1]
 
         def alloc(rows):
-            return dict(descriptors=torch.empty((rows, K, 128)), scores=torch.empty((rows, K)), intensity=torch.empty((rows, K)))
+            # like SequencePipeline.alloc_extract(rows, True): it does not know whether pixels will be passed.  NaN poison: an
+            # 'intensity' buffer nothing wrote must never reach the exchange or the matcher (shard.py)
+            return dict(descriptors=torch.empty((rows, K, 128)), scores=torch.empty((rows, K)), intensity=torch.full((rows, K), float("nan")))
 
         runner = ShardedSequenceRunner(extract if in_place else extract_plain, _match, spacing=spacing,
                                        alloc_fn=alloc if halo == "late" else None, halo=halo)
@@ -103,8 +108,10 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="reco
         kw = dict(gather="records") if gather == "records" else dict(gather="padded")
         if gather == "padded+sizes":
             kw["frames_per_rank"] = [b - a for a, b in (shard_bounds(n_frames, world, r) for r in range(world))]
-        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), **kw)
+        pixels = torch.zeros((hi - lo, 1), dtype=torch.uint8) if with_images else None      # stands for this block's frames
+        out = runner.run(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), pixels, **kw)
         assert out["descriptors"].shape[0] == hi - lo and torch.equal(out["descriptors"], _extract(_pack(desc[lo:hi], sc[lo:hi], inten[lo:hi]), None)["descriptors"])
+        assert ("intensity" in out) == with_images
         if halo == "late" and in_place:
             assert calls == [hi - lo], calls           # the block is ONE launch group; the exchange follows it
         else:
@@ -120,11 +127,19 @@ def _worker(rank, world, port, n_frames, spacing, q, in_place=True, gather="reco
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,spacing,in_place,gather,halo",
-                         [(2, 9, 1, True, "records", "early"), (3, 11, 2, True, "padded+sizes", "late"), (2, 4, 2, True, "padded", "late"),
-                          (4, 14, 1, True, "padded+sizes", "late"), (3, 10, 1, False, "records", "late"), (3, 11, 2, True, "records", "early"),
-                          (2, 9, 1, False, "padded", "early"), (4, 14, 1, True, "padded+sizes", "early")])
-def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gather, halo):
+@pytest.mark.parametrize("world,n_frames,spacing,in_place,gather,halo,with_images",
+                         [(2, 9, 1, True, "records", "early", True), (3, 11, 2, True, "padded+sizes", "late", True),
+                          (2, 4, 2, True, "padded", "late", True), (4, 14, 1, True, "padded+sizes", "late", True),
+                          (3, 10, 1, False, "records", "late", True), (3, 11, 2, True, "records", "early", True),
+                          (2, 9, 1, False, "padded", "early", True), (4, 14, 1, True, "padded+sizes", "early", True),
+                          # tokens only (no pixels): no intensity anywhere - the late path must drop alloc_fn's buffer for it
+                          (3, 11, 1, True, "padded+sizes", "late", False), (2, 7, 2, True, "records", "early", False),
+                          # BASELINE configs[4] arithmetic: 8 ranks, a frame count 8 does not divide, spacing 1, the defaults of
+                          # bench.py --gpus 8 (late halo, padded gather with the ranks' frame counts: no size exchange)
+                          (8, 43, 1, True, "padded+sizes", "late", True),
+                          # 8 ranks, spacing 5: a halo of five frames per boundary (blocks of 6 and 7 frames)
+                          (8, 53, 5, True, "padded+sizes", "late", True), (8, 53, 5, True, "records", "early", True)])
+def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gather, halo, with_images):
     from sslam_amd.shard import shard_bounds
     # partition covers every frame exactly once, contiguously
     edges = [shard_bounds(n_frames, world, r) for r in range(world)]
@@ -132,7 +147,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gathe
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place, gather, halo)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, spacing, q, in_place, gather, halo, with_images)) for r in range(world)]
     for p in procs:
         p.start()
     cnt, mt, qual, per_rank, records, rec_per_rank = q.get(timeout=120)
@@ -140,7 +155,7 @@ def test_sharded_equals_single_process(world, n_frames, spacing, in_place, gathe
         p.join(timeout=60)
         assert p.exitcode == 0
     desc, sc, inten = _make_inputs(n_frames)
-    ref = _match(torch.from_numpy(desc), torch.from_numpy(sc), torch.from_numpy(inten), spacing)
+    ref = _match(torch.from_numpy(desc), torch.from_numpy(sc), torch.from_numpy(inten) if with_images else None, spacing)
     assert sum(per_rank) == n_frames - spacing                     # every pair exactly once, boundary pairs included
     assert np.array_equal(cnt, ref["match_count"].numpy())
     assert np.array_equal(mt, ref["matches"].numpy())

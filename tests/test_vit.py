@@ -101,10 +101,16 @@ def test_hip_vit_from_patch_rows_equals_from_image():
     pv = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda", vit=mine.cuda())
     imgs = torch.from_numpy(synth.image_sequence(5)).cuda()
     with torch.no_grad():
+        n_img = lib.launch_count()
         want = pv.vit_hip.forward_features(pv.preprocess(imgs)).clone()
         n0 = lib.launch_count()
         got = pv.tokens_from_images(imgs)
+        n_pat = lib.launch_count() - n0
+    n_img = n0 - n_img
     assert torch.equal(got, want)
+    # one launch group: A0 + im2patch + the forward against A0 (patch rows) + the same forward - a silent fallback to the
+    # fp32 image (preprocess_u8 + im2patch) would give the same tokens but not one launch fewer
+    assert n_pat == n_img - 1, (n_pat, n_img)
     pt = pv.preprocess_patches(imgs)
     assert pt is not None and pt.shape == (5, 784, 768)
 
