@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
+    ap.add_argument("--no-vit-fp32", action="store_true", help="skip the eager fp32 ViT leg (reference numerics for A1) inside --with-vit")
     ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
     ap.add_argument("--no-upload", action="store_true", help="skip the host-resident-frames leg (overlapped H2D feed)")
     ap.add_argument("--tum-root", default=None, help="a TUM RGB-D sequence directory (rgb/*.png ...) for the directory -> matches leg; "
@@ -363,6 +364,54 @@ def main():
                       "equal_to_resident_pass": bool(torch.equal(ouv[cfg.spacing]["matches"], ov["matches"]) and
                                                      torch.equal(ouv["frames"]["descriptors"], ov["descriptors"]))}
             del ouv, pin_v
+        # reference numerics for A1 (the reference's timm ViT is fp32, dino_backbone.py:85): the same pass with the tokens from
+        # the eager fp32 torch definition of the same weights (what DinoBackbone(vit_precision="fp32") runs), its rate, and the
+        # agreement of the bf16 HIP-ViT pass with it on THIS workload: keypoint sets per frame, matches as (cell, cell) pairs
+        fp32_leg = None
+        if not args.no_vit_fp32:
+            vit_mod = pipe_v.vit_hip.vit
+            tok32 = torch.empty((n, 5 + grid * grid, 384), dtype=torch.float32, device=dev)
+            fchunk = max(1, min(32, (64 * 789) // (5 + grid * grid)))
+
+            def tokens_fp32():
+                with torch.no_grad():
+                    for a_ in range(0, n, fchunk):
+                        tok32[a_:a_ + fchunk] = vit_mod.forward_features(pipe_v.preprocess(imgs[a_:a_ + fchunk]))
+                return tok32
+
+            o32 = pipe_v.run(imgs, tokens_fp32())
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            o32 = pipe_v.run(imgs, tokens_fp32())
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t32
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tokens_fp32()
+            e1.record()
+            torch.cuda.synchronize()
+            vit32_ms = e0.elapsed_time(e1)
+            tok16 = pipe_v.tokens_from_images(imgs)
+            tok_rel = float((tok16 - tok32).norm() / tok32.norm())
+            i32, i16 = o32["idx"].cpu().numpy(), ov["idx"].cpu().numpy()
+            kp_same = float(np.mean([np.intersect1d(a_, b_).size / float(np.unique(a_).size) for a_, b_ in zip(i32, i16)]))
+            m32, m16 = o32["matches"].cpu().numpy(), ov["matches"].cpu().numpy()
+            c32, c16 = o32["match_count"].cpu().numpy(), ov["match_count"].cpu().numpy()
+            hit = tot = 0
+            for p_ in range(n - 1):
+                s32 = set(zip(i32[p_][m32[p_, :c32[p_], 0]].tolist(), i32[p_ + 1][m32[p_, :c32[p_], 1]].tolist()))
+                s16 = set(zip(i16[p_][m16[p_, :c16[p_], 0]].tolist(), i16[p_ + 1][m16[p_, :c16[p_], 1]].tolist()))
+                hit += len(s32 & s16)
+                tot += len(s32)
+            fp32_leg = {"value": round(n / dt32, 2), "unit": "frames/s", "ms_per_step": round(dt32 * 1e3, 3),
+                        "what": "images -> A0 -> EAGER fp32 torch ViT (the reference's numerics for A1: rocBLAS / hipBLASLt fp32 GEMMs + "
+                                "torch ops) -> A2..A9 -> M1; same weights as the bf16 HIP-ViT pass beside it",
+                        "vit_ms": round(vit32_ms, 2), "vit_tflops_fp32": round(n * vit_flop / (vit32_ms * 1e-3) / 1e12, 1),
+                        "bf16_vs_fp32_tokens_rel_err": round(tok_rel, 5),
+                        "bf16_vs_fp32_keypoint_set_agreement": round(kp_same, 4),
+                        "bf16_vs_fp32_match_agreement": round(hit / max(tot, 1), 4), "frames": n, "pairs": n - 1,
+                        "matches_fp32": int(tot)}
+            del o32, tok32, tok16
         vit_tf = n * vit_flop / (vit_ms * 1e-3) / 1e12
         vit_leg = {"value": round(n / dtv, 2), "unit": "frames/s", "ms_per_step": round(dtv * 1e3, 3),
                    "roofline": {"bound": "mfma", "kernel": "A0 + sslam_vit_forward (52 launches per 82-frame chunk: row-tile GEMMs, attention, fused MLP)",
@@ -370,7 +419,7 @@ def main():
                                 "launch_ms": round(vit_ms, 3), "flop_per_launch": int(n * vit_flop),
                                 "note": "dense bf16 MFMA peak (spec); a pure bf16 MFMA loop on random data sustains ~1.3-1.5 PFLOP/s on this chip (DVFS)"},
                    "what": "images -> A0 -> HIP ViT-S/16 (A1, bf16 MFMA, random DINOv3-architecture weights) -> A2..A9 -> M1",
-                   "with_upload": vit_up,
+                   "with_upload": vit_up, "fp32_reference_numerics": fp32_leg,
                    "vit_gflop_per_frame": round(vit_flop / 1e9, 2), "matches_per_pair": round(float(ov["match_count"].float().mean().item()), 1)}
         del ov
 

@@ -7,6 +7,11 @@ n_storage_tokens, input_size, model_name`, sub-modules `dino`, `feature_norm`) a
   remote download.  Here `timm` is used when it is importable; otherwise the in-repo DINOv3 ViT-S/16 definition
   (sslam_amd.vit.DinoV3ViT) is instantiated with random weights and a loud warning: load real weights from a LOCAL
   file with `backbone.dino.load_hf_state_dict(...)`.  A ready ViT can also be injected with `dino=`.
+  Whatever module ends up in `self.dino` - timm's, a transformers-keyed one, any nn.Module with a known DINOv3 key
+  layout (sslam_amd.vit.KEY_MAPS) - its WEIGHTS are converted to the in-repo definition at first use on a GPU, the
+  conversion is verified numerically against the module's own forward_features, and A1 then runs on the HIP ViT
+  (sslam_vit_forward).  Only when the conversion fails does the module's own eager forward run, with a warning that
+  says A1 is not on the HIP kernels and why.  `self.dino` itself stays the caller's module.
 * token drop + BatchNorm1d over tokens (dino_backbone.py:91-106) and the bilinear feature gather
   (extract_at_keypoints, :114-152) run as HIP kernels under `torch.no_grad()` on CUDA tensors, honouring
   `self.training` exactly as nn.BatchNorm1d does (the visualize_* scripts leave the backbone in train mode,
@@ -65,19 +70,32 @@ class DinoBackbone(nn.Module):
 
     # -------------------------------------------------------------------------------------------- forward
     def _hip_vit(self, images: torch.Tensor):
-        """HIP execution of the in-repo ViT definition (bf16 MFMA); rebuilt when the ViT's parameters change.  None
-        unless vit_precision == "bf16", the ViT is the in-repo definition, and its parameters live on the images' GPU
-        (a CPU-resident module with CUDA images takes the eager path, which raises torch's usual device error)."""
-        from sslam_amd.vit import DinoV3ViT
+        """HIP execution of the ViT (bf16 MFMA); rebuilt when the ViT's parameters change.  None unless
+        vit_precision == "bf16" and the parameters live on the images' GPU (a CPU-resident module with CUDA images takes
+        the eager path, which raises torch's usual device error).  `self.dino` is the in-repo definition, or ANY module
+        whose weights convert to it (sslam_amd.vit.convert_module: known key layout, ViT-S/16 shapes, tokens verified
+        against the module's own forward) - timm's model in the reference's setup (dino_backbone.py:44-48).  A module that
+        does not convert runs its own eager forward, after one warning that names the reason."""
+        from sslam_amd.vit import DinoV3ViT, convert_module
         from sslam_amd.vit_hip import HipViT
-        if self.vit_precision != "bf16" or not isinstance(self.dino, DinoV3ViT) or not images.is_cuda:
+        if self.vit_precision != "bf16" or not images.is_cuda:
             return None
         ps = list(self.dino.parameters())
-        if ps[0].device != images.device:
+        if not ps or ps[0].device != images.device:
             return None
         key = tuple((p.data_ptr(), p._version) for p in ps)
-        if getattr(self, "_hip_vit_obj", None) is None or self._hip_vit_key != key:
-            self._hip_vit_obj, self._hip_vit_key = HipViT(self.dino, ps[0].device), key
+        if getattr(self, "_hip_vit_key", None) != key:
+            self._hip_vit_obj, self._hip_vit_key, self.hip_vit_status = None, key, None
+            vit, why = (self.dino, "in-repo definition") if isinstance(self.dino, DinoV3ViT) else convert_module(self.dino)
+            if vit is not None:
+                try:
+                    self._hip_vit_obj = HipViT(vit, ps[0].device)
+                except lib.SslamHipError as e:          # converts, but is not ViT-S/16 with 4 register tokens
+                    why = str(e)
+            self.hip_vit_status = why
+            if self._hip_vit_obj is None:
+                warnings.warn(f"DinoBackbone: A1 (the ViT) is NOT running on the HIP kernels - {type(self.dino).__name__} "
+                              f"could not be converted to the in-repo DINOv3 ViT-S/16 ({why}); its own eager forward runs instead")
         return self._hip_vit_obj
 
     def forward_tokens(self, images: torch.Tensor) -> torch.Tensor:

@@ -157,7 +157,8 @@ class ResampleTables:
 class SequencePipeline:
     def __init__(self, cfg: ExtractorConfig, selector_state: dict | None, refiner_state: dict | None, bn_state: dict | None = None,
                  device="cuda", vit=None, empty_shapes: tuple | None = None):
-        """vit: optional sslam_amd.vit.DinoV3ViT - enables run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ...
+        """vit: optional sslam_amd.vit.DinoV3ViT, or any module whose weights convert to it (vit.KEY_MAPS) - enables
+        run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ...
         selector_state / refiner_state None + empty_shapes=(selector hidden, refiner blocks): uninitialised packed buffers,
         to be filled by the rank-0 weight broadcast (shard.pipeline_from_rank0)."""
         self.cfg = cfg
@@ -185,8 +186,16 @@ class SequencePipeline:
         self.tables = ResampleTables(self.device)
         self.vit_hip = None
         if vit is not None:
+            from .vit import DinoV3ViT, convert_module
             from .vit_hip import HipViT
-            self.vit_hip = HipViT(vit, self.device)
+            if not isinstance(vit, DinoV3ViT):
+                # a third-party module (timm's, transformers-keyed, ...): its weights, converted and verified (vit.convert_module);
+                # this pipeline has no eager path, so a module that does not convert is an error here
+                conv, why = convert_module(vit)
+                if conv is None:
+                    raise lib.SslamHipError(f"{type(vit).__name__} cannot run on the HIP ViT: {why}")
+                vit = conv
+            self.vit_hip = HipViT(vit.to(self.device), self.device)
 
     def weight_tensors(self) -> list:
         """Every device buffer of packed weights / BatchNorm state, in a fixed order (6.7 MB fp32 at the shipped shapes)."""

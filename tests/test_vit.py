@@ -38,6 +38,95 @@ def test_vit_definition_matches_transformers_dinov3():
     assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for n, p in hf.named_parameters() if "mask_token" not in n)
 
 
+@pytest.mark.parametrize("layout", ["transformers", "transformers_flat", "dinov3_upstream", "timm_dinov3"])
+def test_foreign_key_layouts_round_trip(layout):
+    """A random DinoV3ViT written out in each known third-party key layout (fused qkv, separate / fused-and-masked biases,
+    other token names and shapes) and read back through load_mapped_state_dict / from_state_dict: identical parameters,
+    identical tokens.  The layouts other than transformers' are unverified against their packages (not installed)."""
+    import foreign_vit
+    from sslam_amd.vit import KEY_MAPS, DinoV3ViT, detect_key_map
+    src = foreign_vit.random_vit(5, depth=3)
+    sd = foreign_vit.foreign_state_dict(src, layout)
+    assert detect_key_map(sd) == layout
+    back = DinoV3ViT.from_state_dict(sd)
+    assert len(back.blocks) == 3 and back.embed_dim == 384 and back.n_register == 4 and back.patch == 16
+    for (n1, p1), (n2, p2) in zip(src.state_dict().items(), back.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    x = torch.randn(1, 3, 48, 64)
+    with torch.no_grad():
+        assert torch.equal(back.forward_features(x), src.forward_features(x))
+    again = DinoV3ViT(depth=3).load_mapped_state_dict(sd, KEY_MAPS[layout], fused_qkv=layout in ("dinov3_upstream", "timm_dinov3"))
+    assert torch.equal(again.blocks[2].v_proj.bias, src.blocks[2].v_proj.bias)
+
+
+def test_foreign_conversion_refuses_what_it_cannot_represent():
+    import foreign_vit
+    from sslam_amd.vit import DinoV3ViT, convert_module
+    src = foreign_vit.random_vit(6, depth=2)
+    sd = foreign_vit.foreign_state_dict(src, "timm_dinov3")
+    sd["blocks.1.attn.k_bias"] = torch.full((384,), 0.1)                   # a k bias that is really applied
+    with pytest.raises(ValueError, match="k bias"):
+        DinoV3ViT.from_state_dict(sd)
+    sd = foreign_vit.foreign_state_dict(src, "dinov3_upstream")
+    del sd["blocks.0.attn.qkv.bias_mask"], sd["blocks.1.attn.qkv.bias_mask"]   # fused bias with a live k part, no mask
+    with pytest.raises(ValueError, match="k bias"):
+        DinoV3ViT.from_state_dict(sd)
+    with pytest.raises(KeyError):
+        DinoV3ViT.from_state_dict({"weight": torch.zeros(3)})
+    # a module in a known layout converts and is verified against its own forward ...
+    good = foreign_vit.ForeignViT.from_vit(src)
+    vit, why = convert_module(good)
+    assert vit is not None and "verified" in why
+    # ... one with the same parameter shapes but another RoPE base does not pass the numeric check
+    vit, why = convert_module(foreign_vit.ForeignViT.from_vit(src, rope_theta=10000.0))
+    assert vit is None and "differ" in why
+    vit, why = convert_module(torch.nn.Linear(3, 3))
+    assert vit is None
+
+
+@pytest.mark.gpu
+def test_foreign_keyed_module_runs_on_the_hip_vit():
+    """The reference's setup (dino_backbone.py:44-48, :85): `self.dino` is a third-party module, not the in-repo class.
+    A module with timm-style parameters (fused qkv, q_bias / v_bias, gamma_1 / gamma_2, reg_token) handed to DinoBackbone
+    ends up on sslam_vit_forward - same tokens, bit for bit, as the in-repo definition with the same weights - and a
+    module that cannot be converted keeps its own eager forward after a warning that says so."""
+    import warnings
+
+    import foreign_vit
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd import lib
+    src = foreign_vit.random_vit(7)
+    x = torch.randn(3, 3, 448, 448, device="cuda")
+    own = DinoBackbone(input_size=448, dino=src).cuda()
+    with torch.no_grad():
+        want = own.forward_tokens(x).clone()
+    bb = DinoBackbone(input_size=448, dino=foreign_vit.ForeignViT.from_vit(src)).cuda()
+    assert type(bb.dino).__name__ == "ForeignViT"
+    n0 = lib.launch_count()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")                       # the conversion succeeds: no fallback warning
+        got = bb.forward_tokens(x)
+        feats = bb(x)
+    assert lib.launch_count() - n0 >= 2 * 50, "A1 must have run as HIP launches (sslam_vit_forward)"
+    assert "verified" in bb.hip_vit_status
+    assert torch.equal(got, want) and feats.shape == (3, 28, 28, 384)
+    with torch.no_grad():
+        eager = bb.dino.forward_features(x)
+    assert float((got - eager).norm() / eager.norm()) < 2.5e-2
+    # fp32 reference numerics on request: the module's own forward, no HIP ViT launch
+    ref = DinoBackbone(input_size=448, dino=bb.dino, vit_precision="fp32").cuda()
+    n0 = lib.launch_count()
+    with torch.no_grad():
+        assert torch.equal(ref.forward_tokens(x), eager)
+    assert lib.launch_count() == n0
+    # not convertible: warned, eager
+    odd = DinoBackbone(input_size=448, dino=foreign_vit.ForeignViT.from_vit(src, rope_theta=10000.0)).cuda()
+    with torch.no_grad(), pytest.warns(UserWarning, match="NOT running on the HIP kernels"):
+        t = odd.forward_tokens(x)
+    with torch.no_grad():
+        assert torch.equal(t, odd.dino.forward_features(x))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,frames", [(448, 2), (224, 3), (640, 1), (448, 12), (224, 48)])   # the last two: the throughput launch shapes (3 / 4 column tiles per workgroup)
 def test_hip_vit_matches_fp32_definition(size, frames):
