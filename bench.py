@@ -32,7 +32,7 @@ WORKLOADS = {
     # name: (frames per GPU, image h, w, input_size, keypoints)
     "fr1_desk_613": (613, 480, 640, 448, 500),
     "fr1_xyz_50": (50, 480, 640, 448, 500),
-    "fr2_desk_1024kp": (512, 480, 640, 640, 1024),
+    "fr2_desk_1024kp": (2965, 480, 640, 640, 1024),          # configs[2] at its full length (three launch groups of <= 1024 frames)
     "synthetic_2048kp": (128, 960, 1280, 960, 2048),
     # the multi-GPU configs of BASELINE.json at their own per-GPU share (use with --gpus 4 / --gpus 8):
     "fr3_long_office_4gpu": (647, 480, 640, 448, 500),        # configs[3]: 2 585 frames over 4 GPUs, RCCL gather of match pairs
@@ -187,9 +187,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fr1_desk_613", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=10.0, help="N = 1: seconds of back-to-back steps for the `sustained` rate (0: skip)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
-    ap.add_argument("--no-vit-fp32", action="store_true", help="skip the eager fp32 ViT leg (reference numerics for A1) inside --with-vit")
+    ap.add_argument("--no-vit-fp32", action="store_true", help="skip the fp32-operand HIP ViT leg (reference numerics for A1) of the ViT-inside pass")
     ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
     ap.add_argument("--no-upload", action="store_true", help="skip the host-resident-frames leg (overlapped H2D feed)")
     ap.add_argument("--tum-root", default=None, help="a TUM RGB-D sequence directory (rgb/*.png ...) for the directory -> matches leg; "
@@ -318,6 +319,47 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # additional leg (N = 1): the SUSTAINED rate.  `value` is `steps` passes of ~11 ms, i.e. a burst on a chip whose clock is
+    # power-managed; here the same step loops for `--sustain` seconds (default 10) and the rate - and the dominant kernel's
+    # TFLOP/s from its HIP events - is taken over the LAST half of that time, when clocks and temperature have settled.
+    sustained = None
+    if world == 1 and args.sustain > 0:
+        keep = dict(ev)                  # the timed region's stage events
+        ev.clear()
+        marks, a3_seen = [], []           # event at the end of each step; A3 launches recorded up to it (launch groups per step)
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        k_ = 0
+        while True:
+            out = step()
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record()
+            marks.append(e_)
+            a3_seen.append(len(ev["A3_selector_saliency"]))
+            k_ += 1
+            if k_ % 4 == 0:
+                marks[-3].synchronize()    # keep the launch queue a few steps deep, not seconds deep
+                if time.perf_counter() - ts0 >= args.sustain:
+                    break
+        torch.cuda.synchronize()
+        total_s = time.perf_counter() - ts0
+        ms_from_first = [0.0] + [marks[0].elapsed_time(m_) for m_ in marks[1:]]
+        span = ms_from_first[-1]
+        i0 = next(i for i, t_ in enumerate(ms_from_first) if t_ >= span / 2)        # first step that ends in the last half
+        win_ms = span - ms_from_first[i0]
+        nwin = len(marks) - 1 - i0
+        a3 = float(np.sum([a.elapsed_time(b) for a, b in ev["A3_selector_saliency"][a3_seen[i0]:]])) / max(nwin, 1)   # ms per step
+        cells_s = grid * grid
+        conv_flop_s = n * cells_s * pipe.selector.hidden * (9 * 384) * 2 + n * cells_s * pipe.selector.hidden * 2
+        sustained = {"seconds": round(total_s, 2), "steps": len(marks), "window_s": round(win_ms * 1e-3, 2), "window_steps": nwin,
+                     "value": round(n * nwin / (win_ms * 1e-3), 2), "unit": "frames/s",
+                     "a3_ms_per_step": round(a3, 4), "a3_tflops": round(conv_flop_s / (a3 * 1e-3) / 1e12, 2),
+                     "a3_frac_of_fp32_matrix_peak": round(conv_flop_s / (a3 * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                     "first_half_frames_s": round(n * i0 / (ms_from_first[i0] * 1e-3), 2) if i0 else None,
+                     "ratio_to_burst_value": round((n * nwin / (win_ms * 1e-3)) / (n * args.steps / dt), 4)}
+        ev.clear()
+        ev.update(keep)
+
     # additional leg (N = 1): the same pass with the tokens computed on the GPU by the HIP ViT-S/16 (A1, random weights
     # of the DINOv3 architecture - pretrained weights are a remote fetch): images -> A0 -> A1 -> A2 .. M1
     vit_leg = None
@@ -370,27 +412,37 @@ def main():
         fp32_leg = None
         if not args.no_vit_fp32:
             vit_mod = pipe_v.vit_hip.vit
-            tok32 = torch.empty((n, 5 + grid * grid, 384), dtype=torch.float32, device=dev)
-            fchunk = max(1, min(32, (64 * 789) // (5 + grid * grid)))
-
-            def tokens_fp32():
-                with torch.no_grad():
-                    for a_ in range(0, n, fchunk):
-                        tok32[a_:a_ + fchunk] = vit_mod.forward_features(pipe_v.preprocess(imgs[a_:a_ + fchunk]))
-                return tok32
-
-            o32 = pipe_v.run(imgs, tokens_fp32())
+            pipe_32 = SequencePipeline(cfg, ssd, rsd, device=dev, vit=vit_mod, vit_precision="fp32")     # sslam_vit_forward_f32
+            pipe_32.run(imgs[:min(n, 64)])
             torch.cuda.synchronize()
             t32 = time.perf_counter()
-            o32 = pipe_v.run(imgs, tokens_fp32())
+            o32 = pipe_32.run(imgs)
             torch.cuda.synchronize()
             dt32 = time.perf_counter() - t32
+            tok32 = pipe_32.tokens_from_images(imgs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tokens_fp32()
+            pipe_32.tokens_from_images(imgs, out=tok32)
             e1.record()
             torch.cuda.synchronize()
             vit32_ms = e0.elapsed_time(e1)
+            # beside it: the eager torch evaluation of the same weights (rocBLAS / hipBLASLt fp32 GEMMs + torch ops) on a sample
+            ne = min(n, 128)
+            fchunk = max(1, min(32, (64 * 789) // (5 + grid * grid)))
+            toke = torch.empty((ne, 5 + grid * grid, 384), dtype=torch.float32, device=dev)
+
+            def tokens_eager():
+                with torch.no_grad():
+                    for a_ in range(0, ne, fchunk):
+                        toke[a_:a_ + fchunk] = vit_mod.forward_features(pipe_v.preprocess(imgs[a_:a_ + fchunk]))
+
+            tokens_eager()
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            tokens_eager()
+            torch.cuda.synchronize()
+            eager_ms = (time.perf_counter() - te) * 1e3
+            rel_hip_eager = float((tok32[:ne] - toke).norm() / toke.norm())
             tok16 = pipe_v.tokens_from_images(imgs)
             tok_rel = float((tok16 - tok32).norm() / tok32.norm())
             i32, i16 = o32["idx"].cpu().numpy(), ov["idx"].cpu().numpy()
@@ -403,15 +455,21 @@ def main():
                 s16 = set(zip(i16[p_][m16[p_, :c16[p_], 0]].tolist(), i16[p_ + 1][m16[p_, :c16[p_], 1]].tolist()))
                 hit += len(s32 & s16)
                 tot += len(s32)
+            tf32 = n * vit_flop / (vit32_ms * 1e-3) / 1e12
             fp32_leg = {"value": round(n / dt32, 2), "unit": "frames/s", "ms_per_step": round(dt32 * 1e3, 3),
-                        "what": "images -> A0 -> EAGER fp32 torch ViT (the reference's numerics for A1: rocBLAS / hipBLASLt fp32 GEMMs + "
-                                "torch ops) -> A2..A9 -> M1; same weights as the bf16 HIP-ViT pass beside it",
-                        "vit_ms": round(vit32_ms, 2), "vit_tflops_fp32": round(n * vit_flop / (vit32_ms * 1e-3) / 1e12, 1),
+                        "what": "images -> A0 -> HIP ViT-S/16 with fp32 operands on the fp32 matrix pipe (sslam_vit_forward_f32: the "
+                                "reference's numerics for A1) -> A2..A9 -> M1; same weights as the bf16 HIP-ViT pass beside it",
+                        "roofline": {"bound": "mfma", "kernel": "sslam_vit_forward_f32 (gemm_f32_kernel x 5 + attn_f32_kernel + LayerNorm per layer)",
+                                     "achieved": round(tf32, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(tf32 / FP32_MATRIX_PEAK_TFLOPS, 4), "launch_ms": round(vit32_ms, 2)},
+                        "eager_torch_fp32": {"vit_frames_s": round(ne / (eager_ms * 1e-3), 1), "frames": ne,
+                                             "vit_tflops": round(ne * vit_flop / (eager_ms * 1e-3) / 1e12, 1),
+                                             "hip_fp32_vs_eager_tokens_rel_err": float(f"{rel_hip_eager:.3e}")},
                         "bf16_vs_fp32_tokens_rel_err": round(tok_rel, 5),
                         "bf16_vs_fp32_keypoint_set_agreement": round(kp_same, 4),
                         "bf16_vs_fp32_match_agreement": round(hit / max(tot, 1), 4), "frames": n, "pairs": n - 1,
                         "matches_fp32": int(tot)}
-            del o32, tok32, tok16
+            del o32, tok32, tok16, toke, pipe_32
         vit_tf = n * vit_flop / (vit_ms * 1e-3) / 1e12
         vit_leg = {"value": round(n / dtv, 2), "unit": "frames/s", "ms_per_step": round(dtv * 1e3, 3),
                    "roofline": {"bound": "mfma", "kernel": "A0 + sslam_vit_forward (52 launches per 82-frame chunk: row-tile GEMMs, attention, fused MLP)",
@@ -639,6 +697,8 @@ def main():
             "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "frame_ranges": ranges,
             "matches_per_pair": round(float(out["match_count"].float().mean().item()), 1),
         }
+        if sustained is not None:
+            res["sustained"] = sustained
         if world == 1 and not args.no_vit:
             res["with_vit"] = vit_leg
         if latency is not None:

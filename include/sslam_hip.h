@@ -260,6 +260,25 @@ int sslam_vit_forward(const float *images_chw, int n_frames, int size, const ssl
 int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, const sslam_vit_weights_t *weights_host_struct,
                               void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
 
+/* ---- A1 with the reference's numerics: the same forward in fp32 (the reference's timm model runs in fp32,
+ * dino_backbone.py:85) on v_mfma_f32_32x32x2_f32 - fp32 operands, fma-chain contractions, fp32 LayerNorm / softmax / erf-GELU /
+ * residual stream.  Agrees with an fp32 torch evaluation of the same weights to ~1e-5 relative (summation order).
+ * All pointers DEVICE pointers to fp32; matrices are the nn.Linear weights AS THEY ARE, (n_out, k_in) row-major, nothing
+ * folded or packed: wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), bqkv likewise with zeros for the k rows; ls1 / ls2 the
+ * LayerScale vectors; patch_w the Conv2d weight viewed as (384, 768); prefix, rope_cos / rope_sin as in sslam_vit_weights_t.
+ * Workspace: sslam_vit_f32_workspace_bytes(n_frames, size) bytes (x, LayerNorm output, q / k / v, MLP hidden: 13.7 KB per token). */
+typedef struct {
+    const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ls1, *ln2_g, *ln2_b, *wup, *bup, *wdown, *bdown, *ls2;
+} sslam_vit_layer_f32_t;
+typedef struct {
+    const float *patch_w, *patch_b, *prefix;
+    sslam_vit_layer_f32_t layer[12];
+    const float *norm_g, *norm_b, *rope_cos, *rope_sin;
+} sslam_vit_weights_f32_t;
+long long sslam_vit_f32_workspace_bytes(int n_frames, int size);
+int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *weights_host_struct,
+                          void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,425 @@
+// vit_f32.hip - A1 with the REFERENCE'S numerics: the DINOv3 ViT-S/16 forward in fp32 (the reference's timm model is fp32,
+// dino_backbone.py:85) on v_mfma_f32_32x32x2_f32 - every contraction an fp32 fma chain in increasing k, fp32 LayerNorm,
+// softmax, GELU (erf) and residual stream.  Tolerance-level parity with the eager torch fp32 definition (sslam_amd/vit.py)
+// at ~1e-5 relative (summation order differs); vit.hip is the bf16-operand throughput form of the same forward.
+//
+// The fp32 matrix pipe runs at 1/16 of the bf16 rate (64 cycles per 32x32x2 MFMA and SIMD), so every kernel here is bound
+// by its MFMAs and nothing else needs to be clever: GEMM operands go global -> registers -> LDS (KP8 image, one
+// ds_read_b128 per four MFMA steps) with one tile of look-ahead; LayerNorm is its own pass; the MLP's hidden activation
+// makes a round trip through HBM (10 MB per frame and layer, ~3 % of the layer's matrix time).
+//   gemm_f32_kernel<ALoad, Epi>   128 x 128 tile per workgroup, 4 waves x (64 x 64), K in steps of 32
+//   attn_f32_kernel               flash-style: a wave owns 32 queries (registers), keys in tiles of 32 through LDS;
+//                                 S^T = K Q^T and O^T = V^T P^T keep every per-query quantity on one lane pair, and the
+//                                 accumulator registers of S^T ARE the B operand of the second product
+//   ln_rows_f32_kernel            two-pass LayerNorm, one wave per row
+#include "common.h"
+
+namespace {
+
+constexpr int FD = 384, FH = 6, FHD = 64, FMLP = 1536, FPATCH = 16, FPREFIX = 5, FLAYERS = 12;
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLDK = 36;     // LDS row stride 144 B: conflict-free ds_read_b128 / ds_write_b128
+
+// ------------------------------------------------------------------------------------------------ A-operand views
+struct ARows {                // a row-major fp32 matrix
+    const float *p;
+    int ld;
+    __device__ __forceinline__ const float *at(long long row, int k) const { return p + row * ld + k; }
+};
+struct AIm2Patch {            // the (n * G * G, 768) patch matrix of a planar fp32 image, k = c * 256 + ky * 16 + kx, never materialised
+    const float *img;
+    int size, G;
+    __device__ __forceinline__ const float *at(long long row, int k) const {
+        const int cells = G * G;
+        const long long f = row / cells;
+        const int p = (int)(row - f * cells), py = p / G, px = p - py * G;
+        const int c = k >> 8, ky = (k >> 4) & 15, kx = k & 15;
+        return img + ((f * 3 + c) * size + py * FPATCH + ky) * size + px * FPATCH + kx;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------ epilogues
+// acc layout (A = activations, B = weights): register e of lane (r, h) is row crow(e, h), column r of a 32 x 32 tile
+struct EpiPatch {             // x[frame][5 + patch] = acc + bias
+    const float *b;
+    float *x;
+    int cells, T;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const long long row = m0 + mt * 32 + crow(e, h);
+                if (row >= M) continue;
+                const long long f = row / cells;
+                float *dst = x + (f * T + FPREFIX + (row - f * cells)) * FD + n0 + r;
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) dst[nt * 32] = acc[mt][nt][e] + b[n0 + nt * 32 + r];
+            }
+    }
+};
+struct EpiQKV {               // + bias, RoPE on the patch tokens of q and k, scatter to (frame, head, token, 64)
+    const float *b, *cosv, *sinv;
+    float *q, *k, *v;
+    int T;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        const int which = n0 / FD, head = (n0 % FD) / FHD;            // a wave's 64 columns are exactly one head of q, k or v
+        float *dst = which == 0 ? q : (which == 1 ? k : v);
+        const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const long long row = m0 + mt * 32 + crow(e, h);
+                if (row >= M) continue;
+                const long long f = row / T;
+                const int t = (int)(row - f * T);
+                float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
+                if (which < 2 && t >= FPREFIX) {
+                    // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
+                    const float *c = cosv + (long long)(t - FPREFIX) * FHD, *s = sinv + (long long)(t - FPREFIX) * FHD;
+                    const float o0 = v0 * c[r] - v1 * s[r], o1 = v1 * c[32 + r] + v0 * s[32 + r];
+                    v0 = o0;
+                    v1 = o1;
+                }
+                float *o = dst + ((f * FH + head) * T + t) * FHD;
+                o[r] = v0;
+                o[32 + r] = v1;
+            }
+    }
+};
+struct EpiResidual {          // x += ls * (acc + bias)
+    const float *b, *ls;
+    float *x;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int col = n0 + nt * 32 + r;
+            const float bv = b[col], lv = ls[col];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const long long row = m0 + mt * 32 + crow(e, h);
+                    if (row < M) x[row * FD + col] += lv * (acc[mt][nt][e] + bv);
+                }
+        }
+    }
+};
+struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch F.gelu default)
+    const float *b;
+    float *hid;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int col = n0 + nt * 32 + r;
+            const float bv = b[col];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const long long row = m0 + mt * 32 + crow(e, h);
+                    const float v = acc[mt][nt][e] + bv;
+                    if (row < M) hid[row * FMLP + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------------- GEMM
+// C (M x N) = A (M x K) . W^T, W an nn.Linear weight (N, K) row-major; N % 128 == 0, K % 32 == 0.  One fma chain per
+// output in increasing k.  n tiles fastest in blockIdx: the workgroups that share an A tile run together (L2).
+template <class ALoad, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(ALoad al, const float *__restrict__ W, int K, long long M, int ntn, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLDK], Ws[GBN * GLDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)(blockIdx.x / ntn) * GBM;
+    const int n0 = (blockIdx.x % ntn) * GBN;
+    // staging: item = (row, group of 8 k); a thread moves rows tid / 4 and 64 + tid / 4, group tid % 4 of both operands
+    const int srow = tid >> 2, sg = tid & 3;
+    long long ar0 = m0 + srow, ar1 = m0 + 64 + srow;
+    if (ar0 > M - 1) ar0 = M - 1;
+    if (ar1 > M - 1) ar1 = M - 1;
+    float4 pa[4], pw[4];
+    auto fetch = [&](int k0) {
+        const float *a0 = al.at(ar0, k0 + 8 * sg), *a1 = al.at(ar1, k0 + 8 * sg);
+        const float *w0 = W + (long long)(n0 + srow) * K + k0 + 8 * sg, *w1 = W + (long long)(n0 + 64 + srow) * K + k0 + 8 * sg;
+        pa[0] = *reinterpret_cast<const float4 *>(a0);
+        pa[1] = *reinterpret_cast<const float4 *>(a0 + 4);
+        pa[2] = *reinterpret_cast<const float4 *>(a1);
+        pa[3] = *reinterpret_cast<const float4 *>(a1 + 4);
+        pw[0] = *reinterpret_cast<const float4 *>(w0);
+        pw[1] = *reinterpret_cast<const float4 *>(w0 + 4);
+        pw[2] = *reinterpret_cast<const float4 *>(w1);
+        pw[3] = *reinterpret_cast<const float4 *>(w1 + 4);
+    };
+    auto stash = [&]() {
+        float4 ev, od;
+        kp8_split(pa[0], pa[1], ev, od);
+        *reinterpret_cast<float4 *>(As + srow * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(As + srow * GLDK + 8 * sg + 4) = od;
+        kp8_split(pa[2], pa[3], ev, od);
+        *reinterpret_cast<float4 *>(As + (64 + srow) * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(As + (64 + srow) * GLDK + 8 * sg + 4) = od;
+        kp8_split(pw[0], pw[1], ev, od);
+        *reinterpret_cast<float4 *>(Ws + srow * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(Ws + srow * GLDK + 8 * sg + 4) = od;
+        kp8_split(pw[2], pw[3], ev, od);
+        *reinterpret_cast<float4 *>(Ws + (64 + srow) * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(Ws + (64 + srow) * GLDK + 8 * sg + 4) = od;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0.0f;
+    fetch(0);
+    stash();
+    __syncthreads();
+    const float *Ar = As + (wm * 64 + r) * GLDK + 4 * h, *Wr = Ws + (wn * 64 + r) * GLDK + 4 * h;
+    for (int k0 = 0; k0 < K; k0 += GBK) {
+        const bool more = k0 + GBK < K;
+        if (more) fetch(k0 + GBK);                 // in flight during the 64 MFMAs below
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            // KP8 image: the float4 at 8 g + 4 h holds k = 8 g + 2 s + h, s = 0..3 -> MFMA step 4 g + s
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ar + 8 * g), a1 = *reinterpret_cast<const f32x4 *>(Ar + 32 * GLDK + 8 * g);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Wr + 8 * g), b1 = *reinterpret_cast<const f32x4 *>(Wr + 32 * GLDK + 8 * g);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                acc[0][0] = mfma32(a0[s], b0[s], acc[0][0]);
+                acc[0][1] = mfma32(a0[s], b1[s], acc[0][1]);
+                acc[1][0] = mfma32(a1[s], b0[s], acc[1][0]);
+                acc[1][1] = mfma32(a1[s], b1[s], acc[1][1]);
+            }
+        }
+        __syncthreads();                           // every wave is through with this tile
+        if (more) {
+            stash();
+            __syncthreads();
+        }
+    }
+    epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
+}
+
+template <class ALoad, class Epi>
+int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hipStream_t st) {
+    const int ntn = N / GBN;
+    const long long blocks = (M + GBM - 1) / GBM * ntn;
+    hipLaunchKernelGGL((gemm_f32_kernel<ALoad, Epi>), dim3((unsigned)blocks), dim3(256), 0, st, al, W, K, M, ntn, epi);
+    sslam_count_launches(1);
+    return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------------ LayerNorm
+// two-pass, one wave per row of 384 (torch.nn.LayerNorm: biased variance, eps inside the square root)
+__global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
+                                                           float eps, long long rows, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = x + row * FD;
+    float v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float2 t = *reinterpret_cast<const float2 *>(p + 128 * j + 2 * lane);
+        v[2 * j] = t.x;
+        v[2 * j + 1] = t.y;
+        s += t.x + t.y;
+    }
+    const float mean = bfly64(s) / (float)FD;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) q += (v[j] - mean) * (v[j] - mean);
+    const float rstd = 1.0f / sqrtf(bfly64(q) / (float)FD + eps);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int c = 128 * j + 2 * lane;
+        float2 o;
+        o.x = (v[2 * j] - mean) * rstd * g[c] + b[c];
+        o.y = (v[2 * j + 1] - mean) * rstd * g[c + 1] + b[c + 1];
+        *reinterpret_cast<float2 *>(out + row * FD + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(64) void prefix_rows_f32_kernel(const float *__restrict__ prefix, int T, float *__restrict__ x) {
+    const int lane = threadIdx.x, i = blockIdx.x % FPREFIX;
+    const long long row = (long long)(blockIdx.x / FPREFIX) * T + i;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        *reinterpret_cast<float2 *>(x + row * FD + 128 * j + 2 * lane) = *reinterpret_cast<const float2 *>(prefix + i * FD + 128 * j + 2 * lane);
+}
+
+// ------------------------------------------------------------------------------------------------------ attention
+// q, k, v (n * 6, T, 64) fp32 -> y (n, T, 384), softmax(q k^T / 8) v.  A wave owns 32 queries: its query rows live in 32
+// registers as the B operand of S^T = K Q^T (lane (r, h) holds q[r][2 s + h] of step s), so accumulator register e of lane
+// (r, h) is the score of key crow(e, h) against query r - running maximum and row sum are lane-local (+ one xor-32), and
+// register e, exponentiated, is directly the B operand (keys crow(e, 0), crow(e, 1)) of step e of O^T = V^T P^T.
+constexpr int AW = 5, AKT = 32, ALDK = 68;      // waves per workgroup (789 tokens = 25 query tiles = 5 x 5), keys per tile
+__global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                            float *__restrict__ y, int T, int nbh, int subs) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][AKT * ALDK], Vs[2][AKT * FHD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    // XCD-aware order: workgroup b runs on XCD b % 8; the `subs` workgroups of one (frame, head) stay on one XCD (K / V in its L2)
+    const int b = blockIdx.x, chunk = b / (8 * subs), within = b % (8 * subs);
+    const int bh = chunk * 8 + within % 8, sub = within / 8;
+    if (bh >= nbh) return;
+    const int qt = sub * AW + wave;
+    const int n_qt = (T + 31) / 32;
+    const bool wave_on = qt < n_qt;                               // a wave without queries still helps staging
+    const int qi = min(qt * 32 + r, T - 1);
+    const float *qp = q + ((long long)bh * T + qi) * FHD, *kp = k + (long long)bh * T * FHD, *vp = v + (long long)bh * T * FHD;
+    float qreg[32];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
+        qreg[2 * i] = (h ? t.y : t.x) * 0.125f;                   // 1 / sqrt(64): exact
+        qreg[2 * i + 1] = (h ? t.w : t.z) * 0.125f;
+    }
+    // staging: K tile = 32 keys x 8 groups of 8 (threads 0..255, KP8 image); V tile = 32 keys x 16 float4 (512 items)
+    float4 pk[2], pv[2];
+    const int skey = tid >> 3, sg = tid & 7;
+    auto fetch = [&](int key0) {
+        if (tid < 256) {
+            const float *src = kp + (long long)min(key0 + skey, T - 1) * FHD + 8 * sg;
+            pk[0] = *reinterpret_cast<const float4 *>(src);
+            pk[1] = *reinterpret_cast<const float4 *>(src + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int it = tid + j * 64 * AW;
+            if (it < AKT * 16) pv[j] = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + (it >> 4), T - 1) * FHD + 4 * (it & 15));
+        }
+    };
+    auto stash = [&](int buf) {
+        if (tid < 256) {
+            float4 ev, od;
+            kp8_split(pk[0], pk[1], ev, od);
+            *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg]) = ev;
+            *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg + 4]) = od;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int it = tid + j * 64 * AW;
+            if (it < AKT * 16) *reinterpret_cast<float4 *>(&Vs[buf][(it >> 4) * FHD + 4 * (it & 15)]) = pv[j];
+        }
+    };
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = 0.0f;
+    float m = -1.0e30f, l = 0.0f;
+    const int n_kt = (T + AKT - 1) / AKT;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_kt) fetch((kt + 1) * AKT);
+        if (wave_on) {
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e] = 0.0f;
+            const float *A = &Ks[buf][r * ALDK + 4 * h];
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
+#pragma unroll
+                for (int st = 0; st < 4; st++) s = mfma32(a[st], qreg[4 * g + st], s);
+            }
+            float mx = m;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                if (kt * AKT + crow(e, h) >= T) s[e] = -INFINITY;          // only the last tile has such keys
+                mx = fmaxf(mx, s[e]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float alpha = __expf(m - mx);
+            m = mx;
+            float ps = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                s[e] = __expf(s[e] - mx);
+                ps += s[e];
+            }
+            l = l * alpha + ps;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                o[0][e] *= alpha;
+                o[1][e] *= alpha;
+            }
+            // O^T += V^T P^T: step e multiplies keys (crow(e, 0), crow(e, 1)); A operand = V[key(h)][32 dt + r]
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float *vr = &Vs[buf][crow(e, h) * FHD + r];
+                o[0] = mfma32(vr[0], s[e], o[0]);
+                o[1] = mfma32(vr[32], s[e], o[1]);
+            }
+        }
+        if (kt + 1 < n_kt) stash(buf ^ 1);          // the other buffer: last read in iteration kt - 1, behind the barrier below
+        __syncthreads();
+    }
+    if (!wave_on || qt * 32 + r >= T) return;
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int frame = bh / FH, head = bh % FH;
+    float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 4 * h;
+    // register e of o[dt] is O[query r][32 dt + crow(e, h)]: four consecutive d per group of four registers
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float4 t;
+            t.x = o[dt][4 * g] * inv;
+            t.y = o[dt][4 * g + 1] * inv;
+            t.z = o[dt][4 * g + 2] * inv;
+            t.w = o[dt][4 * g + 3] * inv;
+            *reinterpret_cast<float4 *>(dst + 32 * dt + 8 * g) = t;
+        }
+}
+
+inline size_t ws_align(long long b) { return ((size_t)b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" long long sslam_vit_f32_workspace_bytes(int n_frames, int size) {
+    if (n_frames <= 0 || size <= 0 || size % FPATCH) return SSLAM_E_INVALID;
+    const long long G = size / FPATCH, T = G * G + FPREFIX, rows = (long long)n_frames * T;
+    return (long long)(ws_align(rows * FD * 4) * 2 + ws_align(rows * FD * 4 * 3) + ws_align(rows * FMLP * 4));   // x, y, qkv, hidden
+}
+
+extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *w, void *workspace,
+                                     long long workspace_bytes, float *tokens_out, void *stream) {
+    if (!images_chw || !w || !workspace || !tokens_out || n_frames <= 0 || size <= 0 || size % FPATCH) return SSLAM_E_INVALID;
+    if (workspace_bytes < sslam_vit_f32_workspace_bytes(n_frames, size)) return SSLAM_E_INVALID;
+    if (((uintptr_t)images_chw | (uintptr_t)workspace | (uintptr_t)tokens_out) & 15) return SSLAM_E_INVALID;
+    const int G = size / FPATCH, cells = G * G, T = cells + FPREFIX;
+    const long long rows = (long long)n_frames * T, prow = (long long)n_frames * cells;
+    if (rows * FMLP > 0x7fffffffLL * 16) return SSLAM_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    char *p = (char *)workspace;
+    float *x = (float *)p;    p += ws_align(rows * FD * 4);
+    float *y = (float *)p;    p += ws_align(rows * FD * 4);
+    float *q = (float *)p, *k = q + rows * FD, *v = k + rows * FD;    p += ws_align(rows * FD * 4 * 3);
+    float *hid = (float *)p;
+    int rc = launch_gemm(AIm2Patch{images_chw, size, G}, w->patch_w, 3 * FPATCH * FPATCH, prow, FD, EpiPatch{w->patch_b, x, cells, T}, st);
+    if (rc != SSLAM_OK) return rc;
+    hipLaunchKernelGGL(prefix_rows_f32_kernel, dim3(n_frames * FPREFIX), dim3(64), 0, st, w->prefix, T, x);
+    sslam_count_launches(1);
+    const unsigned ln_grid = (unsigned)((rows + 3) / 4);
+    const int n_qt = (T + 31) / 32, subs = (n_qt + AW - 1) / AW, nbh = n_frames * FH;
+    for (int L = 0; L < FLAYERS; L++) {
+        const sslam_vit_layer_f32_t &ly = w->layer[L];
+        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
+        sslam_count_launches(1);
+        if ((rc = launch_gemm(ARows{y, FD}, ly.wqkv, FD, rows, 3 * FD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((nbh + 7) / 8 * 8 * subs)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs);
+        sslam_count_launches(1);
+        if ((rc = launch_gemm(ARows{y, FD}, ly.wo, FD, rows, FD, EpiResidual{ly.bo, ly.ls1, x}, st)) != SSLAM_OK) return rc;
+        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
+        sslam_count_launches(1);
+        if ((rc = launch_gemm(ARows{y, FD}, ly.wup, FD, rows, FMLP, EpiGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm(ARows{hid, FMLP}, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
+    }
+    hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
+    SSLAM_CHECK_LAUNCH();
+    return SSLAM_OK;
+}

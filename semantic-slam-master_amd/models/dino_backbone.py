@@ -31,14 +31,18 @@ class DinoBackbone(nn.Module):
     def __init__(self, model_name: str = "vit_small_patch16_dinov3.lvd1689m", input_size: int = 448, freeze: bool = True,
                  dino: nn.Module | None = None, vit_precision: str = "bf16"):
         """The first three arguments are the reference's (dino_backbone.py:25-30).  `vit_precision` says how the frozen
-        in-repo ViT runs on a GPU under no_grad: "bf16" = the HIP ViT-S/16 (bf16 MFMA operands, fp32 accumulation and
-        fp32 LayerNorm / softmax / residual; tokens within rel 2.5e-2 / cos > 0.995 of the fp32 definition - keypoint
-        and match agreement with the fp32 path is MEASURED in tests/test_gpu_harness.py, it is not bit-exact), "fp32" =
-        the eager fp32 torch definition (what the reference's timm model computes).  Every entry point that needs
-        tokens (forward(), harness.SequenceMatcher) goes through forward_tokens(), so they agree with each other."""
+        ViT runs on a GPU under no_grad:
+          "bf16"  the HIP ViT-S/16 with bf16 MFMA operands (fp32 accumulation, LayerNorm, softmax, residual): the throughput
+                  form; tokens within rel 2.5e-2 / cos > 0.995 of the fp32 definition - keypoint and match agreement with the
+                  fp32 path is MEASURED (tests/test_gpu_harness.py, bench.py `with_vit.fp32_reference_numerics`), not bit-exact;
+          "fp32"  the HIP ViT-S/16 with fp32 operands on the fp32 matrix pipe (sslam_vit_forward_f32): the REFERENCE'S numerics
+                  for A1 (its timm model is fp32), within ~1e-5 relative of the eager torch evaluation;
+          "eager" the module's own torch forward (no HIP kernel for A1).
+        Every entry point that needs tokens (forward(), harness.SequenceMatcher) goes through forward_tokens(), so they
+        agree with each other."""
         super().__init__()
-        if vit_precision not in ("bf16", "fp32"):
-            raise ValueError(f"vit_precision must be 'bf16' or 'fp32', got {vit_precision!r}")
+        if vit_precision not in ("bf16", "fp32", "eager"):
+            raise ValueError(f"vit_precision must be 'bf16', 'fp32' or 'eager', got {vit_precision!r}")
         self.vit_precision = vit_precision
         self.model_name = model_name
         self.input_size = input_size
@@ -70,26 +74,26 @@ class DinoBackbone(nn.Module):
 
     # -------------------------------------------------------------------------------------------- forward
     def _hip_vit(self, images: torch.Tensor):
-        """HIP execution of the ViT (bf16 MFMA); rebuilt when the ViT's parameters change.  None unless
-        vit_precision == "bf16" and the parameters live on the images' GPU (a CPU-resident module with CUDA images takes
+        """HIP execution of the ViT (bf16 or fp32 operands, by vit_precision); rebuilt when the ViT's parameters change.
+        None for vit_precision == "eager" and unless the parameters live on the images' GPU (a CPU-resident module with CUDA images takes
         the eager path, which raises torch's usual device error).  `self.dino` is the in-repo definition, or ANY module
         whose weights convert to it (sslam_amd.vit.convert_module: known key layout, ViT-S/16 shapes, tokens verified
         against the module's own forward) - timm's model in the reference's setup (dino_backbone.py:44-48).  A module that
         does not convert runs its own eager forward, after one warning that names the reason."""
         from sslam_amd.vit import DinoV3ViT, convert_module
-        from sslam_amd.vit_hip import HipViT
-        if self.vit_precision != "bf16" or not images.is_cuda:
+        from sslam_amd.vit_hip import HipViT, HipViTF32
+        if self.vit_precision == "eager" or not images.is_cuda:
             return None
         ps = list(self.dino.parameters())
         if not ps or ps[0].device != images.device:
             return None
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (self.vit_precision,) + tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_hip_vit_key", None) != key:
             self._hip_vit_obj, self._hip_vit_key, self.hip_vit_status = None, key, None
             vit, why = (self.dino, "in-repo definition") if isinstance(self.dino, DinoV3ViT) else convert_module(self.dino)
             if vit is not None:
                 try:
-                    self._hip_vit_obj = HipViT(vit, ps[0].device)
+                    self._hip_vit_obj = (HipViT if self.vit_precision == "bf16" else HipViTF32)(vit, ps[0].device)
                 except lib.SslamHipError as e:          # converts, but is not ViT-S/16 with 4 register tokens
                     why = str(e)
             self.hip_vit_status = why

@@ -37,6 +37,16 @@ class VitWeights(C.Structure):
                 ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
+class VitLayerF32(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ls1", "ln2_g", "ln2_b", "wup", "bup",
+                                          "wdown", "bdown", "ls2")]
+
+
+class VitWeightsF32(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("prefix", C.c_void_p), ("layer", VitLayerF32 * 12),
+                ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+
+
 class RefinerLayout(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("total", C.c_longlong), ("in_w", C.c_longlong), ("in_b", C.c_longlong),
                 ("blk", (C.c_longlong * 8) * 8), ("out_w", C.c_longlong), ("out_b", C.c_longlong)]
@@ -64,7 +74,7 @@ EXPORTS = [
     "sslam_bn_tokens_bf16copy", "sslam_refiner_bf16_bytes", "sslam_refiner_pack_bf16_host", "sslam_refine_bf16", "sslam_gather_refine_bf16",
     "sslam_workspace_bytes", "sslam_selector_saliency_workspace_bytes", "sslam_sim_argmax_workspace_bytes",
     "sslam_selector_saliency_ws", "sslam_sim_argmax_ws", "sslam_test_set_knob",
-    "sslam_preprocess_u8_patches", "sslam_vit_forward_patches",
+    "sslam_preprocess_u8_patches", "sslam_vit_forward_patches", "sslam_vit_f32_workspace_bytes", "sslam_vit_forward_f32",
 ]
 
 
@@ -116,6 +126,9 @@ def lib():
         L.sslam_vit_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
         L.sslam_vit_forward_patches.argtypes = [p, i, i, C.POINTER(VitWeights), p, ll, p, p]
+        L.sslam_vit_f32_workspace_bytes.restype = C.c_longlong
+        L.sslam_vit_f32_workspace_bytes.argtypes = [i, i]
+        L.sslam_vit_forward_f32.argtypes = [p, i, i, C.POINTER(VitWeightsF32), p, ll, p, p]
         _lib = L
     return _lib
 
@@ -501,4 +514,22 @@ def vit_forward(images_chw, weights: VitWeights, workspace, out=None):
     _run("vit_forward", lib().sslam_vit_forward, (images_chw, workspace, out,),
          _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(),
                                    _dp(out))
+    return out
+
+
+def vit_f32_workspace_bytes(n_frames: int, size: int) -> int:
+    b = int(lib().sslam_vit_f32_workspace_bytes(n_frames, size))
+    if b < 0:
+        _check(b, "vit_f32_workspace_bytes")
+    return b
+
+
+def vit_forward_f32(images_chw, weights: VitWeightsF32, workspace, out=None):
+    """(n, 3, S, S) fp32 -> tokens (n, 5 + (S/16)^2, 384) fp32 by the fp32-operand HIP ViT (reference numerics for A1)."""
+    n, _, size, _ = images_chw.shape
+    t = 5 + (size // 16) ** 2
+    if out is None:
+        out = torch.empty((n, t, C_FEAT), dtype=torch.float32, device=images_chw.device)
+    _run("vit_forward_f32", lib().sslam_vit_forward_f32, (images_chw, workspace, out,),
+         _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(), _dp(out))
     return out

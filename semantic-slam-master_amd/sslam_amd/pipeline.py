@@ -156,9 +156,10 @@ class ResampleTables:
 
 class SequencePipeline:
     def __init__(self, cfg: ExtractorConfig, selector_state: dict | None, refiner_state: dict | None, bn_state: dict | None = None,
-                 device="cuda", vit=None, empty_shapes: tuple | None = None):
+                 device="cuda", vit=None, empty_shapes: tuple | None = None, vit_precision: str = "bf16"):
         """vit: optional sslam_amd.vit.DinoV3ViT, or any module whose weights convert to it (vit.KEY_MAPS) - enables
-        run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ...
+        run(images, tokens=None): images -> A0 -> HIP ViT (A1) -> ...; vit_precision "bf16" (throughput form, bf16 MFMA
+        operands) or "fp32" (the reference's numerics for A1: fp32 operands on the fp32 matrix pipe, csrc/vit_f32.hip)
         selector_state / refiner_state None + empty_shapes=(selector hidden, refiner blocks): uninitialised packed buffers,
         to be filled by the rank-0 weight broadcast (shard.pipeline_from_rank0)."""
         self.cfg = cfg
@@ -195,7 +196,14 @@ class SequencePipeline:
                 if conv is None:
                     raise lib.SslamHipError(f"{type(vit).__name__} cannot run on the HIP ViT: {why}")
                 vit = conv
-            self.vit_hip = HipViT(vit.to(self.device), self.device)
+            if vit_precision not in ("bf16", "fp32"):
+                raise ValueError(f"vit_precision must be 'bf16' or 'fp32', got {vit_precision!r}")
+            if vit_precision == "fp32":
+                from .vit_hip import HipViTF32
+                self.vit_hip = HipViTF32(vit.to(self.device), self.device)
+            else:
+                self.vit_hip = HipViT(vit.to(self.device), self.device)
+        self.vit_precision = vit_precision
 
     def weight_tensors(self) -> list:
         """Every device buffer of packed weights / BatchNorm state, in a fixed order (6.7 MB fp32 at the shipped shapes)."""
@@ -237,7 +245,8 @@ class SequencePipeline:
         th, tv = self.tables.get(h, w, size, False)
         for a in range(0, n, span):
             b = min(a + span, n)
-            patches = lib.preprocess_u8_patches(images_u8[a:b], size, th, tv)
+            # the fp32 ViT consumes the fp32 image (its patch embedding is an fp32 contraction too); bf16: the patch rows
+            patches = lib.preprocess_u8_patches(images_u8[a:b], size, th, tv) if self.vit_precision == "bf16" else None
             if patches is not None:
                 self.vit_hip.forward_features(None, out=out[a:b], chunk=vit_chunk, patches=patches, size=size)
             else:

@@ -123,3 +123,61 @@ class HipViT:
         for a in starts:
             launch(a, self._side_ws[0])
         return out
+
+
+class HipViTF32:
+    """The same forward with the REFERENCE'S numerics (fp32 operands on the fp32 matrix pipe, sslam_vit_forward_f32,
+    csrc/vit_f32.hip): what DinoBackbone(vit_precision="fp32") runs on a GPU.  The weights are handed over as they are -
+    fp32, (n_out, k_in) row-major, nothing folded; only q / k / v are concatenated."""
+
+    def __init__(self, vit: DinoV3ViT, device="cuda"):
+        if (vit.embed_dim, vit.heads, vit.patch, vit.n_register, len(vit.blocks)) != (384, 6, 16, 4, 12):
+            raise lib.SslamHipError("the HIP ViT is built for ViT-S/16 with 4 register tokens (384 / 6 heads / 12 layers)")
+        if vit.blocks[0].up_proj.out_features != 1536:
+            raise lib.SslamHipError("MLP width must be 1536")
+        self.vit, self.device = vit, torch.device(device)
+        self._keep, self._rope, self._ws = [], {}, None
+        self.w = lib.VitWeightsF32()
+        f = self._f32
+        self.w.patch_w, self.w.patch_b = f(vit.patch_embed.weight.reshape(384, 768)), f(vit.patch_embed.bias)
+        self.w.prefix = f(torch.cat([vit.cls_token[0], vit.register_tokens[0]], dim=0))
+        for i, b in enumerate(vit.blocks):
+            ly = self.w.layer[i]
+            ly.ln1_g, ly.ln1_b = f(b.norm1.weight), f(b.norm1.bias)
+            ly.wqkv = f(torch.cat([b.q_proj.weight, b.k_proj.weight, b.v_proj.weight], dim=0))
+            ly.bqkv = f(torch.cat([b.q_proj.bias, torch.zeros_like(b.q_proj.bias), b.v_proj.bias]))
+            ly.wo, ly.bo, ly.ls1 = f(b.o_proj.weight), f(b.o_proj.bias), f(b.ls1)
+            ly.ln2_g, ly.ln2_b = f(b.norm2.weight), f(b.norm2.bias)
+            ly.wup, ly.bup = f(b.up_proj.weight), f(b.up_proj.bias)
+            ly.wdown, ly.bdown, ly.ls2 = f(b.down_proj.weight), f(b.down_proj.bias), f(b.ls2)
+        self.w.norm_g, self.w.norm_b = f(vit.norm.weight), f(vit.norm.bias)
+
+    def _f32(self, t):
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t.data_ptr()
+
+    @staticmethod
+    def chunk_frames(size: int) -> int:
+        """Frames per launch group: bounds the workspace (13.7 KB per token: 64 frames at 448 x 448 = 0.7 GB)."""
+        return max(1, (64 * 789) // (5 + (size // 16) ** 2))
+
+    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed)."""
+        n, _, s, s2 = images.shape
+        assert s == s2 and s % 16 == 0 and images.is_cuda
+        g = s // 16
+        if g not in self._rope:
+            cos, sin = self.vit.rope_tables(g, g, self.device)
+            self._rope[g] = (cos.float().contiguous(), sin.float().contiguous())
+        self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
+        step = chunk or self.chunk_frames(s)
+        need = lib.vit_f32_workspace_bytes(min(n, step), s)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=images.device)
+        x = images.detach().float().contiguous()
+        if out is None:
+            out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
+        for a in range(0, n, step):
+            lib.vit_forward_f32(x[a:a + step], self.w, self._ws, out=out[a:a + step])
+        return out

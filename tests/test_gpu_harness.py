@@ -234,19 +234,28 @@ def test_run_directory_with_the_hip_vit(T, tmp_path):
 
 
 def test_vit_precision_agreement(T, pipe):
-    """bf16 HIP ViT vs the fp32 definition on the same weights and frames: how many keypoints / matches agree.
-    (Random ViT weights give a flat, noise-like saliency field - the hardest case for a discontinuous selector.)"""
+    """bf16 HIP ViT vs the fp32 definition (eager torch) on the same weights and frames: how many keypoints / matches agree.
+    (Random ViT weights give a flat, noise-like saliency field - the hardest case for a discontinuous selector.)
+    And the fp32-operand HIP ViT (vit_precision="fp32", the reference's numerics on the HIP kernels) against the same
+    eager evaluation: tokens within 1e-4, keypoint sets and matches (as cell pairs) >= 99.9 % identical."""
     from models.dino_backbone import DinoBackbone
     from sslam_amd.vit import DinoV3ViT
     T.manual_seed(5)
     vit = DinoV3ViT().eval()
     imgs = T.from_numpy(synth.image_sequence(6)).cuda()
     outs = {}
-    for prec in ("bf16", "fp32"):
+    for prec in ("bf16", "fp32", "eager"):
         bb = DinoBackbone(input_size=448, dino=vit, vit_precision=prec).cuda()
         with T.no_grad():
             tok = bb.forward_tokens(pipe.preprocess(imgs)).float().contiguous()
-        outs[prec] = (tok, pipe.run(imgs, tok))
+        outs[prec] = (tok, {k: v.clone() for k, v in pipe.run(imgs, tok).items()})
+    hip32 = outs["fp32"]
+    outs["fp32"] = outs["eager"]               # the reference evaluation below is the eager one
+    rel32 = float((hip32[0] - outs["eager"][0]).norm() / outs["eager"][0].norm())
+    i_h, i_e = hip32[1]["idx"].cpu().numpy(), outs["eager"][1]["idx"].cpu().numpy()
+    kp32 = np.mean([len(set(a) & set(b)) / len(set(b)) for a, b in zip(i_h, i_e)])
+    print(f"\nViT fp32 HIP vs eager: token rel err {rel32:.2e}, keypoint-set agreement {kp32:.4f}")
+    assert rel32 <= 1e-4 and kp32 >= 0.999
     tb, tf = outs["bf16"][0], outs["fp32"][0]
     rel = float((tb - tf).norm() / tf.norm())
     ib, i32 = outs["bf16"][1]["idx"].cpu().numpy(), outs["fp32"][1]["idx"].cpu().numpy()

@@ -227,10 +227,12 @@ def test_backbone_vit_precision_flag_and_device_guard():
         pass
     assert bb._hip_vit(_Img(0)) is None
     assert DinoBackbone(input_size=32, dino=vit, vit_precision="fp32")._hip_vit(_Img(0)) is None
+    assert DinoBackbone(input_size=32, dino=vit, vit_precision="eager")._hip_vit(_Img(0)) is None
     with torch.no_grad():
-        f = bb(x)                                      # eager fp32 definition on CPU, both precisions agree there
+        f = bb(x)                                      # eager fp32 definition on CPU, all precisions agree there
         f32 = DinoBackbone(input_size=32, dino=vit, vit_precision="fp32")(x)
-    assert f.shape == (1, 2, 2, 384) and torch.equal(f, f32)
+        fe = DinoBackbone(input_size=32, dino=vit, vit_precision="eager")(x)
+    assert f.shape == (1, 2, 2, 384) and torch.equal(f, f32) and torch.equal(f, fe)
 
 
 def test_unsupported_dims_fall_back_to_eager_on_cpu_too():
