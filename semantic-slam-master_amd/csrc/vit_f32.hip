@@ -39,21 +39,26 @@ struct AIm2Patch {            // the (n * G * G, 768) patch matrix of a planar f
 
 // ------------------------------------------------------------------------------------------------------ epilogues
 // acc layout (A = activations, B = weights): register e of lane (r, h) is row crow(e, h), column r of a 32 x 32 tile
+// Every epilogue first gathers what it needs (clamped rows: no predicate in front of a load, so the loads of all 64 outputs
+// of a lane go out together), then computes, then stores under the row predicate: a load-wait-store chain per output
+// costs a memory round trip each (64 of them measured as long as the whole k loop of a K = 384 GEMM).
 struct EpiPatch {             // x[frame][5 + patch] = acc + bias
     const float *b;
     float *x;
     int cells, T;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const long long row = m0 + mt * 32 + crow(e, h);
-                if (row >= M) continue;
-                const long long f = row / cells;
-                float *dst = x + (f * T + FPREFIX + (row - f * cells)) * FD + n0 + r;
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) dst[nt * 32] = acc[mt][nt][e] + b[n0 + nt * 32 + r];
+                const unsigned row = (unsigned)(m0 + mt * 32 + crow(e, h));
+                const unsigned f = row / (unsigned)cells;
+                float *dst = x + ((long long)f * T + FPREFIX + (row - f * cells)) * FD + n0 + r;
+                if (row < M) {
+                    dst[0] = acc[mt][0][e] + b0;
+                    dst[32] = acc[mt][1][e] + b1;
+                }
             }
     }
 };
@@ -66,42 +71,62 @@ struct EpiQKV {               // + bias, RoPE on the patch tokens of q and k, sc
         float *dst = which == 0 ? q : (which == 1 ? k : v);
         const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int me = 0; me < 4; me++) {            // 8 rows at a time: bounded temporaries (three workgroups per CU by registers)
+            const int mt = me >> 1, e0 = 8 * (me & 1);
+            float c0[8], c1[8], s0[8], s1[8];
+            unsigned fr[8], tk[8];
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const long long row = m0 + mt * 32 + crow(e, h);
-                if (row >= M) continue;
-                const long long f = row / T;
-                const int t = (int)(row - f * T);
-                float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
-                if (which < 2 && t >= FPREFIX) {
-                    // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
-                    const float *c = cosv + (long long)(t - FPREFIX) * FHD, *s = sinv + (long long)(t - FPREFIX) * FHD;
-                    const float o0 = v0 * c[r] - v1 * s[r], o1 = v1 * c[32 + r] + v0 * s[32 + r];
-                    v0 = o0;
-                    v1 = o1;
-                }
-                float *o = dst + ((f * FH + head) * T + t) * FHD;
-                o[r] = v0;
-                o[32 + r] = v1;
+            for (int j = 0; j < 8; j++) {
+                const int e = e0 + j;
+                const unsigned row = min((unsigned)(m0 + mt * 32 + crow(e, h)), (unsigned)(M - 1));
+                fr[j] = row / (unsigned)T;
+                tk[j] = row - fr[j] * T;
+                // prefix tokens (and v) are not rotated: cos = 1, sin = 0 (table row 0 is read and discarded)
+                const bool rot = which < 2 && tk[j] >= FPREFIX;
+                const long long tb = (long long)(rot ? tk[j] - FPREFIX : 0) * FHD;
+                const float cc0 = cosv[tb + r], cc1 = cosv[tb + 32 + r], ss0 = sinv[tb + r], ss1 = sinv[tb + 32 + r];
+                c0[j] = rot ? cc0 : 1.0f;
+                c1[j] = rot ? cc1 : 1.0f;
+                s0[j] = rot ? ss0 : 0.0f;
+                s1[j] = rot ? ss1 : 0.0f;
             }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int e = e0 + j;
+                // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
+                const float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
+                float *o = dst + (((long long)fr[j] * FH + head) * T + tk[j]) * FHD;
+                if (m0 + mt * 32 + crow(e, h) < M) {
+                    o[r] = v0 * c0[j] - v1 * s0[j];
+                    o[32 + r] = v1 * c1[j] + v0 * s1[j];
+                }
+            }
+        }
     }
 };
 struct EpiResidual {          // x += ls * (acc + bias)
     const float *b, *ls;
     float *x;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        const float bv0 = b[n0 + r], bv1 = b[n0 + 32 + r], lv0 = ls[n0 + r], lv1 = ls[n0 + 32 + r];
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const int col = n0 + nt * 32 + r;
-            const float bv = b[col], lv = ls[col];
+        for (int mt = 0; mt < 2; mt++) {            // 16 rows at a time: bounded temporaries
+            float xv[2][16];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int e = 0; e < 16; e++) {
+                long long row = m0 + mt * 32 + crow(e, h);
+                if (row > M - 1) row = M - 1;
+                xv[0][e] = x[row * FD + n0 + r];
+                xv[1][e] = x[row * FD + n0 + 32 + r];
+            }
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const long long row = m0 + mt * 32 + crow(e, h);
-                    if (row < M) x[row * FD + col] += lv * (acc[mt][nt][e] + bv);
+            for (int e = 0; e < 16; e++) {
+                const long long row = m0 + mt * 32 + crow(e, h);
+                if (row < M) {
+                    x[row * FD + n0 + r] = xv[0][e] + lv0 * (acc[mt][0][e] + bv0);
+                    x[row * FD + n0 + 32 + r] = xv[1][e] + lv1 * (acc[mt][1][e] + bv1);
                 }
+            }
         }
     }
 };
@@ -119,7 +144,8 @@ struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch 
                 for (int e = 0; e < 16; e++) {
                     const long long row = m0 + mt * 32 + crow(e, h);
                     const float v = acc[mt][nt][e] + bv;
-                    if (row < M) hid[row * FMLP + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    if (row < M) hid[row * FMLP + col] = gl;
                 }
         }
     }
@@ -129,7 +155,7 @@ struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch 
 // C (M x N) = A (M x K) . W^T, W an nn.Linear weight (N, K) row-major; N % 128 == 0, K % 32 == 0.  One fma chain per
 // output in increasing k.  n tiles fastest in blockIdx: the workgroups that share an A tile run together (L2).
 template <class ALoad, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(ALoad al, const float *__restrict__ W, int K, long long M, int ntn, Epi epi) {
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(ALoad al, const float *__restrict__ W, int K, long long M, int ntn, Epi epi) {
     __shared__ __attribute__((aligned(16))) float As[GBM * GLDK], Ws[GBN * GLDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -176,8 +202,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(ALoad al, const float 
     __syncthreads();
     const float *Ar = As + (wm * 64 + r) * GLDK + 4 * h, *Wr = Ws + (wn * 64 + r) * GLDK + 4 * h;
     for (int k0 = 0; k0 < K; k0 += GBK) {
-        const bool more = k0 + GBK < K;
-        if (more) fetch(k0 + GBK);                 // in flight during the 64 MFMAs below
+        // unconditional (the last iteration re-reads its own tile): behind a branch the loaded registers become phi values that
+        // hipcc copies right after the loads - a wait for the whole memory latency in front of the MFMAs
+        fetch(min(k0 + GBK, K - GBK));             // in flight during the 64 MFMAs below
+        __builtin_amdgcn_sched_barrier(0);         // ... which the scheduler would otherwise sink to their use behind the MFMAs
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             // KP8 image: the float4 at 8 g + 4 h holds k = 8 g + 2 s + h, s = 0..3 -> MFMA step 4 g + s
@@ -192,10 +220,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(ALoad al, const float 
             }
         }
         __syncthreads();                           // every wave is through with this tile
-        if (more) {
-            stash();
-            __syncthreads();
-        }
+        // unconditional as well (the last one is never read): a use only behind `if (more)` lets LLVM sink the loads into that
+        // block, i.e. behind the MFMAs
+        stash();
+        __syncthreads();
     }
     epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
 }
@@ -254,8 +282,8 @@ __global__ __launch_bounds__(64) void prefix_rows_f32_kernel(const float *__rest
 // registers as the B operand of S^T = K Q^T (lane (r, h) holds q[r][2 s + h] of step s), so accumulator register e of lane
 // (r, h) is the score of key crow(e, h) against query r - running maximum and row sum are lane-local (+ one xor-32), and
 // register e, exponentiated, is directly the B operand (keys crow(e, 0), crow(e, 1)) of step e of O^T = V^T P^T.
-constexpr int AW = 5, AKT = 32, ALDK = 68;      // waves per workgroup (789 tokens = 25 query tiles = 5 x 5), keys per tile
-__global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+constexpr int AW = 4, AKT = 32, ALDK = 68;      // waves per workgroup (4 x 32 queries; one wave per SIMD and workgroup), keys per tile
+__global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                             float *__restrict__ y, int T, int nbh, int subs) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AKT * ALDK], Vs[2][AKT * FHD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -275,33 +303,24 @@ __global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restri
         qreg[2 * i] = (h ? t.y : t.x) * 0.125f;                   // 1 / sqrt(64): exact
         qreg[2 * i + 1] = (h ? t.w : t.z) * 0.125f;
     }
-    // staging: K tile = 32 keys x 8 groups of 8 (threads 0..255, KP8 image); V tile = 32 keys x 16 float4 (512 items)
-    float4 pk[2], pv[2];
-    const int skey = tid >> 3, sg = tid & 7;
+    // staging, 256 threads: K tile = 32 keys x 8 groups of 8 (one item per thread, KP8 image); V tile = 32 keys x 16 float4
+    // (two per thread: keys tid / 16 and 16 + tid / 16)
+    float4 pk0, pk1, pv0, pv1;
+    const int skey = tid >> 3, sg = tid & 7, vkey = tid >> 4, vq = tid & 15;
     auto fetch = [&](int key0) {
-        if (tid < 256) {
-            const float *src = kp + (long long)min(key0 + skey, T - 1) * FHD + 8 * sg;
-            pk[0] = *reinterpret_cast<const float4 *>(src);
-            pk[1] = *reinterpret_cast<const float4 *>(src + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int it = tid + j * 64 * AW;
-            if (it < AKT * 16) pv[j] = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + (it >> 4), T - 1) * FHD + 4 * (it & 15));
-        }
+        const float *src = kp + (long long)min(key0 + skey, T - 1) * FHD + 8 * sg;
+        pk0 = *reinterpret_cast<const float4 *>(src);
+        pk1 = *reinterpret_cast<const float4 *>(src + 4);
+        pv0 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + vkey, T - 1) * FHD + 4 * vq);
+        pv1 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + 16 + vkey, T - 1) * FHD + 4 * vq);
     };
     auto stash = [&](int buf) {
-        if (tid < 256) {
-            float4 ev, od;
-            kp8_split(pk[0], pk[1], ev, od);
-            *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg]) = ev;
-            *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg + 4]) = od;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int it = tid + j * 64 * AW;
-            if (it < AKT * 16) *reinterpret_cast<float4 *>(&Vs[buf][(it >> 4) * FHD + 4 * (it & 15)]) = pv[j];
-        }
+        float4 ev, od;
+        kp8_split(pk0, pk1, ev, od);
+        *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg]) = ev;
+        *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg + 4]) = od;
+        *reinterpret_cast<float4 *>(&Vs[buf][vkey * FHD + 4 * vq]) = pv0;
+        *reinterpret_cast<float4 *>(&Vs[buf][(16 + vkey) * FHD + 4 * vq]) = pv1;
     };
     f32x16 o[2];
 #pragma unroll
@@ -313,7 +332,8 @@ __global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restri
     __syncthreads();
     for (int kt = 0; kt < n_kt; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < n_kt) fetch((kt + 1) * AKT);
+        fetch(min(kt + 1, n_kt - 1) * AKT);         // unconditional and pinned here: see gemm_f32_kernel
+        __builtin_amdgcn_sched_barrier(0);
         if (wave_on) {
             f32x16 s;
 #pragma unroll
@@ -325,12 +345,20 @@ __global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restri
 #pragma unroll
                 for (int st = 0; st < 4; st++) s = mfma32(a[st], qreg[4 * g + st], s);
             }
+            // the A operands of the second product (V^T fragments) do not depend on the softmax: the first half (d < 32) is
+            // requested now and used after it, the second half (d >= 32) goes out in front of the first half's 16 MFMAs
+            float vf0[16], vf1[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) vf0[e] = Vs[buf][crow(e, h) * FHD + r];
+            __builtin_amdgcn_sched_barrier(0);       // keeps the LDS reads HERE (the scheduler sinks each one to its MFMA otherwise)
+            if (kt == n_kt - 1) {                    // only the last tile can hold keys beyond T
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (kt * AKT + crow(e, h) >= T) s[e] = -INFINITY;
+            }
             float mx = m;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                if (kt * AKT + crow(e, h) >= T) s[e] = -INFINITY;          // only the last tile has such keys
-                mx = fmaxf(mx, s[e]);
-            }
+            for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float alpha = __expf(m - mx);
             m = mx;
@@ -346,15 +374,16 @@ __global__ __launch_bounds__(64 * AW) void attn_f32_kernel(const float *__restri
                 o[0][e] *= alpha;
                 o[1][e] *= alpha;
             }
+#pragma unroll
+            for (int e = 0; e < 16; e++) vf1[e] = Vs[buf][crow(e, h) * FHD + 32 + r];
+            __builtin_amdgcn_sched_barrier(0);
             // O^T += V^T P^T: step e multiplies keys (crow(e, 0), crow(e, 1)); A operand = V[key(h)][32 dt + r]
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float *vr = &Vs[buf][crow(e, h) * FHD + r];
-                o[0] = mfma32(vr[0], s[e], o[0]);
-                o[1] = mfma32(vr[32], s[e], o[1]);
-            }
+            for (int e = 0; e < 16; e++) o[0] = mfma32(vf0[e], s[e], o[0]);
+#pragma unroll
+            for (int e = 0; e < 16; e++) o[1] = mfma32(vf1[e], s[e], o[1]);
         }
-        if (kt + 1 < n_kt) stash(buf ^ 1);          // the other buffer: last read in iteration kt - 1, behind the barrier below
+        stash(buf ^ 1);          // the other buffer: last read in iteration kt - 1, behind the barrier below (unconditional: see the GEMM)
         __syncthreads();
     }
     if (!wave_on || qt * 32 + r >= T) return;

@@ -9,12 +9,13 @@ from sslam_amd import lib
 if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (experiments)
     lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 from sslam_amd.vit import DinoV3ViT
-from sslam_amd.vit_hip import HipViT
+from sslam_amd.vit_hip import HipViT, HipViTF32
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 448
 torch.manual_seed(0)
 vit = DinoV3ViT().cuda().eval()
-hv = HipViT(vit)
+F32 = os.environ.get("SSLAM_BENCH_VIT", "bf16") == "fp32"       # the fp32-operand ViT (csrc/vit_f32.hip)
+hv = HipViTF32(vit) if F32 else HipViT(vit)
 T = 5 + (size // 16) ** 2
 flop = 12 * (T * 384 * 1152 * 2 + 2 * 6 * T * T * 64 * 2 + T * 384 * 384 * 2 + 2 * T * 384 * 1536 * 2) + (T - 5) * 768 * 384 * 2
 CH = int(os.environ.get("SSLAM_BENCH_CHUNK", "0"))      # frames per launch group (default: the whole batch in one group)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-kernel times of the HIP ViT alone (rocprofv3 --kernel-trace --stats): bash tools/vit_kstats.sh <tag> <chunk>
+# (SSLAM_BENCH_VIT=fp32 in the environment: the fp32-operand ViT)
 TAG=${1:-vit}; CHUNK=${2:-41}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
