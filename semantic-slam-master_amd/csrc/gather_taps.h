@@ -29,7 +29,11 @@ __device__ __forceinline__ Taps make_taps(const float *feat_frame, int G, float 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int xs = xi + (k & 1), ys = yi + (k >> 1);
-        const bool ok = !(xs < 0 || xs >= G || ys < 0 || ys >= G);
+        // a tap whose weight is exactly 0 is not fetched either: it reads the zero row (0 * 0 instead of f * 0: the same sum
+        // for finite features).  The selector's keypoints are integer cells, and for two thirds of them the normalise /
+        // un-normalise round trip of grid_sample returns the integer exactly - one tap instead of four;
+        // most of the others need two.  The gather is the one HBM-bound phase of the descriptor kernels.
+        const bool ok = !(xs < 0 || xs >= G || ys < 0 || ys >= G) && t.wt[k] != 0.0f;
         const int xc = min(max(xs, 0), G - 1), yc = min(max(ys, 0), G - 1);
         t.src[k] = ok ? feat_frame + ((long long)yc * G + xc) * SSLAM_C : g_zero_row;
     }
