@@ -58,7 +58,7 @@ long long sslam_sim_argmax_workspace_bytes(int n2, int n_pairs);
  * restores the value read from the environment when the library was loaded (else the built-in default).  Not thread-safe against running calls; product code never calls it.  Knobs:
  * SSLAM_M1_VARIANT, SSLAM_CONV_VARIANT, SSLAM_CONV_LATENCY_ROWS, SSLAM_CONV_LAT2_ROWS, SSLAM_CONV_NO_HALO, SSLAM_CONV_TAIL,
  * SSLAM_CONVBF_NO_HALO, SSLAM_CONVBF_TAIL, SSLAM_CONVBF_VARIANT, SSLAM_VIT_NO_FUSED_MLP, SSLAM_BN_FORM,
- * SSLAM_RT_STOP, SSLAM_REFBF_FORM (csrc/common.h says what each selects). */
+ * SSLAM_RT_STOP (csrc/common.h says what each selects). */
 int sslam_test_set_knob(const char *name, long long value, int unset);
 
 /* ---- weight packing (host side, plain C++; run once per checkpoint) ------------------------------------------

@@ -34,7 +34,6 @@ enum sslam_knob_id {
     KNOB_VIT_NO_FUSED_MLP,    // SSLAM_VIT_NO_FUSED_MLP    the two-launch MLP
     KNOB_BN_FORM,             // SSLAM_BN_FORM             1: three-sweep BatchNorm kernel instead of the register-resident one
     KNOB_RT_STOP,             // SSLAM_RT_STOP             probe builds only
-    KNOB_REFBF_FORM,          // SSLAM_REFBF_FORM          1: the column-slab bf16 descriptor MLP (64 rows, 4 waves) instead of the row-resident one
     KNOB_COUNT
 };
 #define SSLAM_KNOB_UNSET (-0x7fffffffffffffffLL - 1)

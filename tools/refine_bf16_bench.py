@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """A6+A7 in the bf16 throughput mode on the bench workload's shape (613 frames x 500 keypoints, 28 x 28 grid): time and
-TFLOP/s of the row-resident kernel (default) and of the round-1 column-slab kernel (SSLAM_REFBF_FORM = 1), fused and x_in
-entries, and the largest difference between the two forms' descriptors.  python tools/refine_bf16_bench.py"""
+TFLOP/s of the fused and the x_in entry.  python tools/refine_bf16_bench.py [libsslam_hip.so variant] [frac]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,15 +37,7 @@ def timed(fn, reps=20):
 
 
 fl = F * K * 1572864
-out = {}
-for form, tag in ((0, "row-resident (96 rows x 12 waves)"), (1, "column-slab (64 rows x 4 waves)")):
-    with lib.knobs(SSLAM_REFBF_FORM=form):
-        d = lib.gather_refine_bf16(feat, kp, ref.packed_bf16, ref.n_blocks).clone()
-        t1 = timed(lambda: lib.gather_refine_bf16(feat, kp, ref.packed_bf16, ref.n_blocks))
-        t2 = timed(lambda: lib.refine_bf16(x, ref.packed_bf16, ref.n_blocks))
-    out[form] = d
-    print(f"{tag:36s}: gather+MLP {t1:6.3f} ms ({fl / t1 / 1e9:7.1f} TF = {fl / t1 / 1e9 / 2500:.3f} of the bf16 peak)   "
-          f"MLP (x_in) {t2:6.3f} ms ({fl / t2 / 1e9:7.1f} TF)", flush=True)
-print(os.path.basename(lib.SO_PATH))
-print(f"max |row-resident - column-slab| = {float((out[0] - out[1]).abs().max()):.3e}  (the forms differ in the summation order of "
-      f"the row statistics only)")
+t1 = timed(lambda: lib.gather_refine_bf16(feat, kp, ref.packed_bf16, ref.n_blocks))
+t2 = timed(lambda: lib.refine_bf16(x, ref.packed_bf16, ref.n_blocks))
+print(f"{os.path.basename(lib.SO_PATH)}: gather+MLP {t1:6.3f} ms ({fl / t1 / 1e9:7.1f} TF = {fl / t1 / 1e9 / 2500:.3f} of the bf16 peak)   "
+      f"MLP (x_in) {t2:6.3f} ms ({fl / t2 / 1e9:7.1f} TF)", flush=True)
