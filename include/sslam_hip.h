@@ -263,9 +263,11 @@ int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, 
 /* ---- A1 with the reference's numerics: the same forward in fp32 (the reference's timm model runs in fp32,
  * dino_backbone.py:85) on v_mfma_f32_32x32x2_f32 - fp32 operands, fma-chain contractions, fp32 LayerNorm / softmax / erf-GELU /
  * residual stream.  Agrees with an fp32 torch evaluation of the same weights to ~1e-5 relative (summation order).
- * All pointers DEVICE pointers to fp32; matrices are the nn.Linear weights AS THEY ARE, (n_out, k_in) row-major, nothing
- * folded or packed: wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), bqkv likewise with zeros for the k rows; ls1 / ls2 the
- * LayerScale vectors; patch_w the Conv2d weight viewed as (384, 768); prefix, rope_cos / rope_sin as in sslam_vit_weights_t.
+ * All pointers DEVICE pointers to fp32; nothing is folded into the weights (ls1 / ls2 are the LayerScale vectors).  The four
+ * per-layer matrices - wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), wo (384, 384), wup (1536, 384), wdown (384, 1536) - are
+ * re-ordered by sslam_vit_f32_pack_linear_host into the MFMA fragment order their kernel streams from L2 (same values, same
+ * size); bqkv has zeros for the k rows; patch_w is the Conv2d weight viewed as (384, 768), as it is; prefix, rope_cos / rope_sin
+ * as in sslam_vit_weights_t.
  * Workspace: sslam_vit_f32_workspace_bytes(n_frames, size) bytes (x, LayerNorm output, q / k / v, MLP hidden: 13.7 KB per token). */
 typedef struct {
     const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ls1, *ln2_g, *ln2_b, *wup, *bup, *wdown, *bdown, *ls2;
@@ -275,6 +277,9 @@ typedef struct {
     sslam_vit_layer_f32_t layer[12];
     const float *norm_g, *norm_b, *rope_cos, *rope_sin;
 } sslam_vit_weights_f32_t;
+/* host helper: fp32 nn.Linear weight (n_out, k_in), n_out % 128 == 0, k_in % 32 == 0 -> element (n, k) at
+ * [n/32][k/8][k%2][n%32][(k%8)/2] */
+int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_in, float *out);
 long long sslam_vit_f32_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *weights_host_struct,
                           void *workspace, long long workspace_bytes, float *tokens_out, void *stream);

@@ -130,14 +130,14 @@ struct EpiResidual {          // x += ls * (acc + bias)
         }
     }
 };
-struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch F.gelu default)
+struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch F.gelu default); columns stored in KP8 order (a GEMM's A operand)
     const float *b;
     float *hid;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            const int col = n0 + nt * 32 + r;
-            const float bv = b[col];
+            const float bv = b[n0 + nt * 32 + r];
+            const int col = kp8(n0 + nt * 32 + r);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -237,8 +237,129 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
     return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
 }
 
+
+// ------------------------------------------------------------------------------------------ GEMM, per-layer form
+// The four GEMMs of a layer (96 % of the GEMM work).  Beside fp32 MFMAs every other vector instruction costs matrix time
+// (fp32 matrix time and vector time of a SIMD add up), so this form is written for instruction COUNT:
+//   * W is PRE-PACKED in MFMA fragment order (sslam_vit_f32_pack_linear_host): a wave fetches the B fragments of its two
+//     column tiles straight from L2 - one 1 KB buffer load per (tile, group of 8 k) with a SCALAR offset, ring of four groups -
+//     no LDS staging, no LDS reads, no address arithmetic for W;
+//   * A's producers (LayerNorm, attention, the GELU epilogue) write their columns in KP8 order, so the A tile goes global ->
+//     registers -> LDS as it is (no shuffle) and is read back with one ds_read_b128 per four MFMA steps; two LDS buffers, one
+//     barrier per k tile, the tile of step t + 1 is stored in front of the MFMAs of step t and the loads of t + 2 follow it.
+// Per k tile and wave: 64 MFMAs beside 8 + 4 loads, 4 LDS stores, 8 LDS reads (the generic form above: ~150 instructions).
+template <class Epi>
+__global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
+                                                                long long M, int ntn, Epi epi) {
+    // + 1 152 floats of padding per buffer: 46 KB per workgroup = exactly THREE workgroups per CU whatever an instantiation's
+    // register count allows - the host sizes its launch groups in whole rounds of 3 x 256 workgroups (HipViTF32.chunk_frames)
+    __shared__ __attribute__((aligned(16))) float As[2][GBM * GLDK + 1152];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform BY CONSTRUCTION: the B loads' scalar offsets depend on it
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)(blockIdx.x / ntn) * GBM;
+    const int n0 = (blockIdx.x % ntn) * GBN;
+    // A staging: thread = (row tid / 2, half tid % 2) moves 16 consecutive (already KP8-ordered) floats of its row per k tile
+    const int srow = tid >> 1, sh = tid & 1;
+    long long ar = m0 + srow;
+    if (ar > M - 1) ar = M - 1;
+    const float *ap = A + ar * lda + 16 * sh;
+    constexpr int ABUF = GBM * GLDK + 1152;
+    float *as_w = &As[0][srow * GLDK + 16 * sh];
+    float4 pa0, pa1, pa2, pa3;
+    auto fetch = [&](int k0) {
+        const float4 *src = reinterpret_cast<const float4 *>(ap + k0);
+        pa0 = src[0];
+        pa1 = src[1];
+        pa2 = src[2];
+        pa3 = src[3];
+    };
+    auto stash = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(as_w + buf * ABUF);
+        dst[0] = pa0;
+        dst[1] = pa1;
+        dst[2] = pa2;
+        dst[3] = pa3;
+    };
+    // B fragments: packed W, fragment (column tile nt, group g) at ((nt * K / 8 + g) * 1024) bytes, lane * 16 inside it
+    const int groups = K / 8;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, 0x7fffffff, 0x00020000);
+    const int nt0 = (n0 + wn * 64) / 32;
+    const int wo0 = nt0 * groups * 1024, wo1 = wo0 + groups * 1024, loff = lane * 16;
+    // ring of four groups (= one k tile), as named registers with compile-time slots (an indexed array ends up in scratch); three
+    // groups in flight.  Vector-memory operations return IN ORDER: a wait for a B fragment also waits for every load issued before
+    // it, so the A tile's loads (the long ones: HBM / MALL) go out right BEHIND the B loads of group 0 - the first B wait that
+    // can see them is three groups (3 072 matrix cycles) later.  (With the A loads at the head of the step and two groups in
+    // flight every step stalled on them: slower than the generic kernel despite a third of its instructions.)
+    f32x4 q00, q01, q10, q11, q20, q21, q30, q31;
+    auto loadb = [&](f32x4 &d0, f32x4 &d1, int G) {
+        d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
+        d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0.0f;
+    const int n_kt = K / GBK;
+    fetch(0);
+    loadb(q00, q01, 0);
+    loadb(q10, q11, 1);
+    loadb(q20, q21, 2);
+    stash(0);
+    fetch(min(1, n_kt - 1) * GBK);
+    __syncthreads();
+    const float *Ar = &As[0][(wm * 64 + r) * GLDK + 4 * h];
+    // one group of 8 k: 2 LDS reads, 16 MFMAs on the B fragments c0 / c1
+    auto mma = [&](const float *Ab, int g, const f32x4 &c0, const f32x4 &c1) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + 8 * g), a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * GLDK + 8 * g);
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            acc[0][0] = mfma32(a0[st], c0[st], acc[0][0]);
+            acc[0][1] = mfma32(a0[st], c1[st], acc[0][1]);
+            acc[1][0] = mfma32(a1[st], c0[st], acc[1][0]);
+            acc[1][1] = mfma32(a1[st], c1[st], acc[1][1]);
+        }
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < n_kt; kt++) {
+        const int buf = kt & 1, G = kt * 4;
+        const float *Ab = Ar + buf * ABUF;
+        // the tile of the NEXT step goes into the other buffer (read last in the previous step, behind its barrier)
+        stash(buf ^ 1);
+        loadb(q30, q31, min(G + 3, groups - 1));
+        fetch(min(kt + 2, n_kt - 1) * GBK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Ab, 0, q00, q01);
+        __builtin_amdgcn_sched_barrier(0);
+        loadb(q00, q01, min(G + 4, groups - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Ab, 1, q10, q11);
+        __builtin_amdgcn_sched_barrier(0);
+        loadb(q10, q11, min(G + 5, groups - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Ab, 2, q20, q21);
+        __builtin_amdgcn_sched_barrier(0);
+        loadb(q20, q21, min(G + 6, groups - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Ab, 3, q30, q31);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
+}
+
+template <class Epi>
+int launch_gemm_rows(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
+    const int ntn = N / GBN;
+    const long long blocks = (M + GBM - 1) / GBM * ntn;
+    hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
+    sslam_count_launches(1);
+    return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------------------------ LayerNorm
-// two-pass, one wave per row of 384 (torch.nn.LayerNorm: biased variance, eps inside the square root)
+// two-pass, one wave per row of 384 (torch.nn.LayerNorm: biased variance, eps inside the square root).  PERM: the columns are
+// written in KP8 order (position of column c inside its group of 8: (0,2,4,6,1,3,5,7)) - the layout gemm_f32_rows_kernel reads
+template <bool PERM>
 __global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
                                                            float eps, long long rows, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -265,7 +386,12 @@ __global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float *__restric
         float2 o;
         o.x = (v[2 * j] - mean) * rstd * g[c] + b[c];
         o.y = (v[2 * j + 1] - mean) * rstd * g[c + 1] + b[c + 1];
-        *reinterpret_cast<float2 *>(out + row * FD + c) = o;
+        if (PERM) {
+            out[row * FD + kp8(c)] = o.x;
+            out[row * FD + kp8(c + 1)] = o.y;
+        } else {
+            *reinterpret_cast<float2 *>(out + row * FD + c) = o;
+        }
     }
 }
 
@@ -390,24 +516,40 @@ __global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__res
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const int frame = bh / FH, head = bh % FH;
-    float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 4 * h;
-    // register e of o[dt] is O[query r][32 dt + crow(e, h)]: four consecutive d per group of four registers
+    float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 2 * h;
+    // register e of o[dt] is O[query r][d = 32 dt + 8 g + 4 h + i], e = 4 g + i.  y is the A operand of the o_proj GEMM: columns in
+    // KP8 order, i.e. inside the group of 8 the even d at positions 0..3 and the odd d at 4..7 - this lane's d = 4 h + {0, 2} go to
+    // positions 2 h, 2 h + 1 and d = 4 h + {1, 3} to 4 + 2 h, 5 + 2 h: two 8-byte stores per group
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            float4 t;
-            t.x = o[dt][4 * g] * inv;
-            t.y = o[dt][4 * g + 1] * inv;
-            t.z = o[dt][4 * g + 2] * inv;
-            t.w = o[dt][4 * g + 3] * inv;
-            *reinterpret_cast<float4 *>(dst + 32 * dt + 8 * g) = t;
+            float2 ev, od;
+            ev.x = o[dt][4 * g] * inv;
+            ev.y = o[dt][4 * g + 2] * inv;
+            od.x = o[dt][4 * g + 1] * inv;
+            od.y = o[dt][4 * g + 3] * inv;
+            *reinterpret_cast<float2 *>(dst + 32 * dt + 8 * g) = ev;
+            *reinterpret_cast<float2 *>(dst + 32 * dt + 8 * g + 4) = od;
         }
 }
 
 inline size_t ws_align(long long b) { return ((size_t)b + 255) & ~(size_t)255; }
 
 }  // namespace
+
+// nn.Linear weight (n_out, k_in) fp32 -> the fragment order gemm_f32_rows_kernel streams: out[nt][g][h][r][s] =
+// w[32 nt + r][8 g + 2 s + h] (one 1 KB fragment per 32 columns x 8 k: lane (r, h) reads its four MFMA steps as one float4)
+extern "C" int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_in, float *out) {
+    if (!w || !out || n_out <= 0 || k_in <= 0 || n_out % GBN || k_in % GBK) return SSLAM_E_INVALID;
+    const int groups = k_in / 8;
+    for (int n = 0; n < n_out; n++)
+        for (int k = 0; k < k_in; k++) {
+            const int nt = n / 32, r = n % 32, g = k / 8, s2 = (k % 8) / 2, h = k % 2;
+            out[((((long long)nt * groups + g) * 2 + h) * 32 + r) * 4 + s2] = w[(long long)n * k_in + k];
+        }
+    return SSLAM_OK;
+}
 
 extern "C" long long sslam_vit_f32_workspace_bytes(int n_frames, int size) {
     if (n_frames <= 0 || size <= 0 || size % FPATCH) return SSLAM_E_INVALID;
@@ -437,18 +579,18 @@ extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int 
     const int n_qt = (T + 31) / 32, subs = (n_qt + AW - 1) / AW, nbh = n_frames * FH;
     for (int L = 0; L < FLAYERS; L++) {
         const sslam_vit_layer_f32_t &ly = w->layer[L];
-        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
+        hipLaunchKernelGGL(ln_rows_f32_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
         sslam_count_launches(1);
-        if ((rc = launch_gemm(ARows{y, FD}, ly.wqkv, FD, rows, 3 * FD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm_rows(y, FD, ly.wqkv, FD, rows, 3 * FD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
         hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((nbh + 7) / 8 * 8 * subs)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs);
         sslam_count_launches(1);
-        if ((rc = launch_gemm(ARows{y, FD}, ly.wo, FD, rows, FD, EpiResidual{ly.bo, ly.ls1, x}, st)) != SSLAM_OK) return rc;
-        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
+        if ((rc = launch_gemm_rows(y, FD, ly.wo, FD, rows, FD, EpiResidual{ly.bo, ly.ls1, x}, st)) != SSLAM_OK) return rc;
+        hipLaunchKernelGGL(ln_rows_f32_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
         sslam_count_launches(1);
-        if ((rc = launch_gemm(ARows{y, FD}, ly.wup, FD, rows, FMLP, EpiGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
-        if ((rc = launch_gemm(ARows{hid, FMLP}, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm_rows(y, FD, ly.wup, FD, rows, FMLP, EpiGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm_rows(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
     }
-    hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
+    hipLaunchKernelGGL(ln_rows_f32_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }

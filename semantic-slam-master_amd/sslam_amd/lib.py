@@ -75,6 +75,7 @@ EXPORTS = [
     "sslam_workspace_bytes", "sslam_selector_saliency_workspace_bytes", "sslam_sim_argmax_workspace_bytes",
     "sslam_selector_saliency_ws", "sslam_sim_argmax_ws", "sslam_test_set_knob",
     "sslam_preprocess_u8_patches", "sslam_vit_forward_patches", "sslam_vit_f32_workspace_bytes", "sslam_vit_forward_f32",
+    "sslam_vit_f32_pack_linear_host",
 ]
 
 
@@ -129,6 +130,7 @@ def lib():
         L.sslam_vit_f32_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_f32_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward_f32.argtypes = [p, i, i, C.POINTER(VitWeightsF32), p, ll, p, p]
+        L.sslam_vit_f32_pack_linear_host.argtypes = [p, i, i, p]
         _lib = L
     return _lib
 
@@ -514,6 +516,14 @@ def vit_forward(images_chw, weights: VitWeights, workspace, out=None):
     _run("vit_forward", lib().sslam_vit_forward, (images_chw, workspace, out,),
          _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(),
                                    _dp(out))
+    return out
+
+
+def pack_vit_f32_linear(w: np.ndarray) -> np.ndarray:
+    """(n_out, k_in) fp32 nn.Linear weight -> the same values in the fragment order of the fp32 ViT's per-layer GEMM."""
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(w.size, np.float32)
+    _check(lib().sslam_vit_f32_pack_linear_host(w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data), "vit_f32_pack_linear")
     return out
 
 

@@ -127,8 +127,8 @@ class HipViT:
 
 class HipViTF32:
     """The same forward with the REFERENCE'S numerics (fp32 operands on the fp32 matrix pipe, sslam_vit_forward_f32,
-    csrc/vit_f32.hip): what DinoBackbone(vit_precision="fp32") runs on a GPU.  The weights are handed over as they are -
-    fp32, (n_out, k_in) row-major, nothing folded; only q / k / v are concatenated."""
+    csrc/vit_f32.hip): what DinoBackbone(vit_precision="fp32") runs on a GPU.  The weights stay fp32 with nothing folded into them;
+    q / k / v are concatenated and the four per-layer matrices re-ordered into the fragment order their GEMM streams."""
 
     def __init__(self, vit: DinoV3ViT, device="cuda"):
         if (vit.embed_dim, vit.heads, vit.patch, vit.n_register, len(vit.blocks)) != (384, 6, 16, 4, 12):
@@ -138,18 +138,18 @@ class HipViTF32:
         self.vit, self.device = vit, torch.device(device)
         self._keep, self._rope, self._ws = [], {}, None
         self.w = lib.VitWeightsF32()
-        f = self._f32
+        f, pk = self._f32, self._packed
         self.w.patch_w, self.w.patch_b = f(vit.patch_embed.weight.reshape(384, 768)), f(vit.patch_embed.bias)
         self.w.prefix = f(torch.cat([vit.cls_token[0], vit.register_tokens[0]], dim=0))
         for i, b in enumerate(vit.blocks):
             ly = self.w.layer[i]
             ly.ln1_g, ly.ln1_b = f(b.norm1.weight), f(b.norm1.bias)
-            ly.wqkv = f(torch.cat([b.q_proj.weight, b.k_proj.weight, b.v_proj.weight], dim=0))
+            ly.wqkv = pk(torch.cat([b.q_proj.weight, b.k_proj.weight, b.v_proj.weight], dim=0))
             ly.bqkv = f(torch.cat([b.q_proj.bias, torch.zeros_like(b.q_proj.bias), b.v_proj.bias]))
-            ly.wo, ly.bo, ly.ls1 = f(b.o_proj.weight), f(b.o_proj.bias), f(b.ls1)
+            ly.wo, ly.bo, ly.ls1 = pk(b.o_proj.weight), f(b.o_proj.bias), f(b.ls1)
             ly.ln2_g, ly.ln2_b = f(b.norm2.weight), f(b.norm2.bias)
-            ly.wup, ly.bup = f(b.up_proj.weight), f(b.up_proj.bias)
-            ly.wdown, ly.bdown, ly.ls2 = f(b.down_proj.weight), f(b.down_proj.bias), f(b.ls2)
+            ly.wup, ly.bup = pk(b.up_proj.weight), f(b.up_proj.bias)
+            ly.wdown, ly.bdown, ly.ls2 = pk(b.down_proj.weight), f(b.down_proj.bias), f(b.ls2)
         self.w.norm_g, self.w.norm_b = f(vit.norm.weight), f(vit.norm.bias)
 
     def _f32(self, t):
@@ -157,10 +157,19 @@ class HipViTF32:
         self._keep.append(t)
         return t.data_ptr()
 
+    def _packed(self, w):
+        """(N, K) nn.Linear weight -> fp32, the same values in the fragment order of the per-layer GEMM (packed by the library)."""
+        t = torch.from_numpy(lib.pack_vit_f32_linear(w.detach().float().cpu().numpy())).to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
     @staticmethod
     def chunk_frames(size: int) -> int:
-        """Frames per launch group: bounds the workspace (13.7 KB per token: 64 frames at 448 x 448 = 0.7 GB)."""
-        return max(1, (64 * 789) // (5 + (size // 16) ** 2))
+        """Frames per launch group: 512 row tiles of 128 tokens.  The per-layer GEMMs run one workgroup per (row tile, 128 columns)
+        at three per CU (768 slots), so 512 row tiles are whole rounds for all four of them (N = 384: 2 rounds, 1 152: 6, 1 536: 8);
+        64 frames = 395 row tiles left the N = 384 GEMMs at 1.54 rounds (a quarter of their time idle).  83 frames at 448 x 448;
+        also bounds the workspace (13.7 KB per token: 0.9 GB)."""
+        return max(1, (512 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
         """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed)."""
