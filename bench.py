@@ -273,20 +273,25 @@ def main():
         return r
 
     def extract_staged(t, im, out=None):
-        """pipe.extract stage by stage (same calls, same buffers), each bracketed by HIP events on the launch stream"""
+        """pipe.extract stage by stage (same calls, same buffers, the same launch groups of pipe.launch_group() frames), each
+        bracketed by HIP events on the launch stream; a stage's time per step is the sum over its launch groups"""
         s = pipe.selector
         o = out if out is not None else pipe.alloc_extract(t.shape[0], True)
-        vit_in = timed("A0_preprocess", lambda: pipe.preprocess(im))
-        feat = timed("A2_bn_tokens", lambda: pipe.features(t))
-        ws = pipe.workspace(t.shape[0], 0)
-        timed("A3_selector_saliency", lambda: lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden, out=o["saliency"], workspace=ws))
-        timed("A45_select_keypoints",
-              lambda: lib.select_keypoints(o["saliency"], cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile,
-                                           out=(o["keypoints_patch"], o["scores"], o["idx"], o["keypoints_pixel"], o["status"])))
-        timed("A67_gather_refine", lambda: lib.gather_refine(feat, o["keypoints_patch"], pipe.refiner.packed, pipe.refiner.n_blocks, out=o["descriptors"]))
-        th, tv = pipe.tables.get(h, w, size, True)
-        timed("A9_intensity", lambda: lib.keypoint_intensity(im, size, th, tv, o["keypoints_pixel"], out=o["intensity"]))
-        del vit_in
+        step_ = pipe.launch_group()
+        for a_ in range(0, t.shape[0], step_):
+            tt, ii = t[a_:a_ + step_], im[a_:a_ + step_]
+            og = {k_: v_[a_:a_ + step_] for k_, v_ in o.items()}
+            vit_in = timed("A0_preprocess", lambda: pipe.preprocess(ii))
+            feat = timed("A2_bn_tokens", lambda: pipe.features(tt))
+            ws = pipe.workspace(tt.shape[0], 0)
+            timed("A3_selector_saliency", lambda: lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden, out=og["saliency"], workspace=ws))
+            timed("A45_select_keypoints",
+                  lambda: lib.select_keypoints(og["saliency"], cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile,
+                                               out=(og["keypoints_patch"], og["scores"], og["idx"], og["keypoints_pixel"], og["status"])))
+            timed("A67_gather_refine", lambda: lib.gather_refine(feat, og["keypoints_patch"], pipe.refiner.packed, pipe.refiner.n_blocks, out=og["descriptors"]))
+            th, tv = pipe.tables.get(h, w, size, True)
+            timed("A9_intensity", lambda: lib.keypoint_intensity(ii, size, th, tv, og["keypoints_pixel"], out=og["intensity"]))
+            del vit_in, feat
         return o
 
     def match_staged(desc, sc, inten, sp):
@@ -459,7 +464,7 @@ def main():
             fp32_leg = {"value": round(n / dt32, 2), "unit": "frames/s", "ms_per_step": round(dt32 * 1e3, 3),
                         "what": "images -> A0 -> HIP ViT-S/16 with fp32 operands on the fp32 matrix pipe (sslam_vit_forward_f32: the "
                                 "reference's numerics for A1) -> A2..A9 -> M1; same weights as the bf16 HIP-ViT pass beside it",
-                        "roofline": {"bound": "mfma", "kernel": "sslam_vit_forward_f32 (gemm_f32_kernel x 5 + attn_f32_kernel + LayerNorm per layer)",
+                        "roofline": {"bound": "mfma", "kernel": "sslam_vit_forward_f32 (per layer: gemm_f32_rows_kernel x 4 + attn_f32_kernel + 2 LayerNorms)",
                                      "achieved": round(tf32, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(tf32 / FP32_MATRIX_PEAK_TFLOPS, 4), "launch_ms": round(vit32_ms, 2)},
                         "eager_torch_fp32": {"vit_frames_s": round(ne / (eager_ms * 1e-3), 1), "frames": ne,

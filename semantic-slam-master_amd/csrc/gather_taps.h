@@ -7,7 +7,7 @@ namespace {
 
 // one all-zero feature row: a tap outside the grid (zero padding) reads it instead of being masked element by element
 // afterwards - 8 selects per keypoint instead of 32 per 8-channel chunk (every instruction a wave issues besides its
-// MFMAs takes issue time from the matrix pipe it shares with the other resident waves)
+// MFMAs takes issue time from the matrix pipe it shares with the other resident waves, DESIGN_HISTORY.md section 9)
 __device__ float g_zero_row[SSLAM_C];
 
 struct Taps {

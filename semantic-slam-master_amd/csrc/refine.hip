@@ -9,7 +9,7 @@
 // (96 of its columns per wave).  ReLU, the residual identity and LayerNorm then work on registers: row statistics are
 // lane-local sums, one xor-32 shuffle and a 4-wave exchange through LDS; the tile is written once per layer in 8-byte
 // pairs.  (The earlier row-per-wave LayerNorm on the LDS tile cost ~1 000 instructions per call, and every instruction
-// a wave issues besides its MFMAs takes issue time from the matrix pipe it shares - DESIGN.md section 9.)
+// a wave issues besides its MFMAs takes issue time from the matrix pipe it shares - DESIGN_HISTORY.md section 9.)
 // The pre-packed weights (3.17 MB, L2-resident, shared by all workgroups) are NOT staged through LDS: they are stored in
 // MFMA-fragment order ([k/8][n][8 floats KP8]) and fetched by buffer loads with scalar (layer, k-group, tile) offsets,
 // 1 KB coalesced per wave-instruction, two k-groups ahead.  A layer's GEMM has no barrier.
@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemm_lds(const float *H, __amdgpu_buffer_rsrc_t 
         }
     // lane's B fragment of k-group g, tile t: 16 B at ((g*N + n)*8 + 4h) floats, n = wn*32*NT + t*32 + r.  Buffer loads:
     // address = descriptor base + 32-bit lane offset (constant) + SCALAR offset of (layer, k-group, tile), so the k loop
-    // carries no vector address arithmetic at all - every non-MFMA instruction costs matrix-pipe issue time
+    // carries no vector address arithmetic at all - every non-MFMA instruction costs matrix-pipe issue time (DESIGN_HISTORY.md section 9)
     const int loff = ((wn * 32 * NT + r) * 2 + h) * 16;
     const float *A = H + (wm * 32 + r) * LDH + 4 * h;
     f32x4 b0[NT], b1[NT], b2[NT];

@@ -44,7 +44,7 @@ __device__ __forceinline__ void gemm_bf16(const bf16 *tile, const unsigned char 
     constexpr int TILES = 4 * NT;   // N / 32
     const int r = lane & 31, h = lane >> 5;
     // buffer loads: descriptor over this layer's weights + 32-bit lane offset + SCALAR (k-step, tile) offset - no vector
-    // address arithmetic in the k loop (every non-MFMA instruction costs matrix-pipe issue time)
+    // address arithmetic in the k loop (every non-MFMA instruction costs matrix-pipe issue time, DESIGN_HISTORY.md section 9)
     const __amdgpu_buffer_rsrc_t wrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(w), 0, KS * TILES * 1024, 0x00020000);
     const int loff = ((wn * NT) * 64 + lane) * 16;

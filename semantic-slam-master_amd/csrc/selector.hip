@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, (BDIRECT && WM == 2) ? 4 : 1) void selector_sa
 
     // per-thread A rows (fixed for the whole K loop).  Loads are buffer loads: descriptor base + 32-bit lane offset of the
     // row's own cell + a SCALAR offset for (tap, channel chunk) - no per-stage vector address arithmetic (every non-MFMA
-    // instruction costs matrix-pipe issue time).  A tap outside the grid reads some other cell (or, outside the
+    // instruction costs matrix-pipe issue time, DESIGN_HISTORY.md section 9).  A tap outside the grid reads some other cell (or, outside the
     // buffer, zeros from the descriptor's range check); it is zeroed at STORE_STAGE by the precomputed 9-bit validity mask.
     const __amdgpu_buffer_rsrc_t frs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, (int)((unsigned)n_rows * (SSLAM_C * 4u)), 0x00020000);

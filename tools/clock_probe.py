@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timing inside the descriptor-MLP workgroups.  Needs the probe build of the kernel:
+"""Phase timing inside the descriptor-MLP workgroups (DESIGN_HISTORY.md section 9).  Needs the probe build of the kernel:
 
     make -C semantic-slam-master_amd/csrc clean all EXTRA=-DSSLAM_CLOCK_PROBE && python tools/clock_probe.py
     make -C semantic-slam-master_amd/csrc clean all        # back to the product build

@@ -14,7 +14,7 @@ import sys
 KEEP = ("selector_saliency_halo_kernel", "selector_saliency", "gather_refine", "sim_argmax", "bn_tokens", "preprocess_kernel", "select_keypoints",
         "intensity_kernel", "match_finalize", "gather_kernel", "gemm_ares_kernel", "gemm_bf16_kernel", "attn_kernel", "ln_rows_kernel",
         "mlp_fused_kernel", "im2patch", "refine_bf16_kernel", "selector_bf16_kernel", "selector_bf16_halo_kernel", "preprocess_fast_kernel", "bn_tokens_reg_kernel", "keys_decode_kernel",
-        "gemm_rt_kernel", "prefix_rows_kernel", "gemm_f32_kernel", "attn_f32_kernel", "ln_rows_f32_kernel")
+        "gemm_rt_kernel", "prefix_rows_kernel", "gemm_f32_rows_kernel", "gemm_f32_kernel", "attn_f32_kernel", "ln_rows_f32_kernel")
 
 
 def short(name):

@@ -51,14 +51,14 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INS
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_vit.json /tmp/pv1 /tmp/pv2 /tmp/pv3 /tmp/pv4 > /dev/null
 echo "[4b] the fp32-operand ViT (reference numerics for A1, csrc/vit_f32.hip): bench, kernel stats, matrix-pipe counters"
 export SSLAM_BENCH_VIT=fp32
-python $ROOT/tools/bench_vit.py 448 8 32 64 128 > $OUT/${TAG}_vit_f32_bench.txt
-rm -rf /tmp/kf && rocprofv3 --kernel-trace --stats -d /tmp/kf -o x --output-format csv -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
+python $ROOT/tools/bench_vit.py 448 8 41 83 166 > $OUT/${TAG}_vit_f32_bench.txt
+rm -rf /tmp/kf && rocprofv3 --kernel-trace --stats -d /tmp/kf -o x --output-format csv -- python $ROOT/tools/bench_vit.py 448 83 > /dev/null 2>&1
 cp $(find /tmp/kf -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_vit_f32_kernel_stats.csv
 rm -rf /tmp/pf1 /tmp/pf2 /tmp/pf3
-PF="--kernel-trace --kernel-include-regex gemm_f32_kernel|attn_f32_kernel|ln_rows_f32 --output-format csv -o x"
-rocprofv3 --pmc FETCH_SIZE $PF -d /tmp/pf1 -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE $PF -d /tmp/pf2 -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU $PF -d /tmp/pf3 -- python $ROOT/tools/bench_vit.py 448 64 > /dev/null 2>&1
+PF="--kernel-trace --kernel-include-regex gemm_f32|attn_f32_kernel|ln_rows_f32 --output-format csv -o x"
+rocprofv3 --pmc FETCH_SIZE $PF -d /tmp/pf1 -- python $ROOT/tools/bench_vit.py 448 83 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE $PF -d /tmp/pf2 -- python $ROOT/tools/bench_vit.py 448 83 > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU $PF -d /tmp/pf3 -- python $ROOT/tools/bench_vit.py 448 83 > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_vit_f32.json /tmp/pf1 /tmp/pf2 /tmp/pf3 > /dev/null
 unset SSLAM_BENCH_VIT
 fi

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints the per-layer ViT table of DESIGN 5b from profiles/<tag>_vit_kernel_stats.csv, _pmc_vit.json and _yardstick.txt.
+"""Prints the per-layer ViT table of DESIGN_HISTORY.md 5b from profiles/<tag>_vit_kernel_stats.csv, _pmc_vit.json and _yardstick.txt.
 usage: vit_table.py [tag] [frames of the profiled launch group]"""
 import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
