@@ -137,6 +137,43 @@ def test_sequence_matcher_extract_from_png(T, tmp_path):
     assert m.dtype == np.int64 and q.dtype == np.float32 and np.array_equal(m, wm) and np.array_equal(q, wq)
 
 
+@pytest.mark.parametrize("tag", ["e2e_g40", "e2e_g60"])
+def test_reference_shaped_harness_on_larger_grids(T, tag):
+    """The reference's own call shape - SequenceMatcher.extract frame by frame, then match_with_quality pair by pair with the CLI
+    thresholds (visualize_matches_sequence.py:69-104, 106-197, 381-388) - through the drop-in DinoBackbone (input_size 640 /
+    960), harness.SequenceMatcher and matching.match_with_quality, against the reference's end-to-end goldens at G = 40 / K = 1024
+    and G = 60 / K = 2048 (tests/e2e_check.py holds the bars: sets, order up to near-tie swaps, values by cell, matches as cell
+    pairs and - where both frames kept their order - as indices)."""
+    import e2e_check
+    import matching
+    from models.dino_backbone import DinoBackbone
+    from sslam_amd.harness import SequenceMatcher
+    from sslam_amd.pipeline import ExtractorConfig
+    from test_models_api import TokenDino
+    g = e2e_check.gold(tag)
+    grid, K, n = int(g["grid"]), int(g["K"]), int(g["n_frames"])
+    toks = synth.token_sequence(n, grid)
+    imgs = synth.image_sequence(n, int(g["height"]), int(g["width"]))
+    bb = DinoBackbone(input_size=16 * grid, dino=TokenDino(), vit_precision="eager")      # tokens are the input here (a stand-in ViT)
+    sm = SequenceMatcher(bb, synth.selector_state(0), synth.refiner_state(0), cfg=ExtractorConfig(input_size=16 * grid, num_keypoints=K))
+    frames = []
+    for i in range(n):
+        bb.dino.tokens = T.from_numpy(toks[i:i + 1]).cuda()
+        out = sm.extract_batch(imgs[i:i + 1])
+        frames.append({k: v[0].cpu().numpy() for k, v in out.items()})
+    px = np.stack([f["keypoints_pixel"] for f in frames])
+    cell = ((px - 8) / 16).astype(np.int64)
+    idx = cell[..., 1] * grid + cell[..., 0]
+    sc = np.stack([f["scores"] for f in frames])
+    desc = np.stack([f["descriptors"] for f in frames])
+    inten = np.stack([f["intensity"] for f in frames])
+
+    def match(a, b):
+        return matching.match_with_quality(desc[a], desc[b], sc[a], sc[b], intensity1=inten[a], intensity2=inten[b], **e2e_check.CLI)
+    rep = e2e_check.check_sequence(tag, idx, sc, desc, inten, match)
+    assert len(rep["pairs"]) >= 8 and all(p["cells_equal"] for p in rep["pairs"])
+
+
 def _assert_same(T, a: dict, b: dict, keys):
     for k in keys:
         assert a[k].dtype == b[k].dtype and T.equal(a[k], b[k]), k

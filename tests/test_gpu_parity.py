@@ -480,7 +480,7 @@ def test_dropin_modules_on_gpu(T, hip):
     from test_models_api import TokenDino
     g = gold("e2e")
     toks = synth.token_sequence(3, 28)
-    bb = DinoBackbone(input_size=448, freeze=True, dino=TokenDino()).cuda()
+    bb = DinoBackbone(input_size=448, freeze=True, dino=TokenDino(), vit_precision="eager").cuda()    # a token stand-in: nothing to convert
     sel = KeypointSelector(384, 256).cuda()
     ref = DescriptorRefiner(384, 384, 128).cuda()
     sel.load_state_dict({k: T.from_numpy(v) for k, v in synth.selector_state(0).items()})
