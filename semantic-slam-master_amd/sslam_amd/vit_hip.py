@@ -136,7 +136,8 @@ class HipViTF32:
         if vit.blocks[0].up_proj.out_features != 1536:
             raise lib.SslamHipError("MLP width must be 1536")
         self.vit, self.device = vit, torch.device(device)
-        self._keep, self._rope, self._ws = [], {}, None
+        self._keep, self._rope = [], {}
+        self._ws, self._side, self.n_streams = [None, None], None, 2      # launch groups alternate between two streams
         self.w = lib.VitWeightsF32()
         f, pk = self._f32, self._packed
         self.w.patch_w, self.w.patch_b = f(vit.patch_embed.weight.reshape(384, 768)), f(vit.patch_embed.bias)
@@ -172,7 +173,9 @@ class HipViTF32:
         return max(1, (512 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
-        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed)."""
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed).  Several launch groups alternate
+        between two side streams (one workspace each), as in HipViT.forward_features: one group's kernels fill the ramps and
+        tails of the other's; the caller's stream semantics are kept."""
         n, _, s, s2 = images.shape
         assert s == s2 and s % 16 == 0 and images.is_cuda
         g = s // 16
@@ -182,11 +185,30 @@ class HipViTF32:
         self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
         step = chunk or self.chunk_frames(s)
         need = lib.vit_f32_workspace_bytes(min(n, step), s)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=images.device)
         x = images.detach().float().contiguous()
         if out is None:
             out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
-        for a in range(0, n, step):
-            lib.vit_forward_f32(x[a:a + step], self.w, self._ws, out=out[a:a + step])
+        starts = list(range(0, n, step))
+        dev = images.device
+        for i in (0, 1) if len(starts) >= 2 and self.n_streams >= 2 else (0,):
+            if self._ws[i] is None or self._ws[i].numel() < need:
+                self._ws[i] = torch.empty(need, dtype=torch.uint8, device=dev)
+        if len(starts) >= 2 and self.n_streams >= 2:
+            cur = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            ready = cur.record_event()
+            for i, a in enumerate(starts):
+                st = self._side[i & 1]
+                if i < 2:
+                    st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    lib.vit_forward_f32(x[a:a + step], self.w, self._ws[i & 1], out=out[a:a + step])
+            for st in self._side:
+                x.record_stream(st)
+                out.record_stream(st)
+                cur.wait_stream(st)
+            return out
+        for a in starts:
+            lib.vit_forward_f32(x[a:a + step], self.w, self._ws[0], out=out[a:a + step])
         return out
