@@ -66,41 +66,93 @@ struct EpiQKV {               // + bias, RoPE on the patch tokens of q and k, sc
     const float *b, *cosv, *sinv;
     float *q, *k, *v;
     int T;
-    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
-        const int which = n0 / FD, head = (n0 % FD) / FHD;            // a wave's 64 columns are exactly one head of q, k or v
+    // FULL: every row of the wave's 64 x 64 tile is inside M (all tiles but the last row tile): stores need no predicate.
+    // Requires T >= 64 (a tile of 64 rows crosses at most one frame boundary); smaller token counts take run_small.
+    template <bool ROPE, bool FULL>
+    __device__ __forceinline__ void run(const f32x16 (&acc)[2][2], float *dst, long long m0, int n0, int r, int h, long long M) const {
+        const int head = (n0 % FD) / FHD;
+        const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
+        // (frame, token) of the wave's first row by ONE division; the 64 rows that follow are reached by adding (T > 64: at most one
+        // frame boundary inside the tile) - 32 integer divisions per lane cost more than the tile's arithmetic.  Destination row of
+        // token index tr = t0 + offset (not wrapped): (f0 * 6 + head) * T + tr, plus 5 T once tr has passed into the next frame
+        const unsigned f0 = (unsigned)(m0 / T);
+        const int t0 = (int)(m0 - (long long)f0 * T);
+        float *base = dst + ((long long)f0 * FH + head) * T * FHD + r;
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {           // 4 rows at a time: their 16 table values are requested together, then used
+            const int mt = blk >> 2, e0 = 4 * (blk & 3);
+            float cc0[4], cc1[4], ss0[4], ss1[4];
+            int tw[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int tr = t0 + mt * 32 + crow(e0 + j, h);
+                tw[j] = tr >= T ? tr - T : tr;
+                if (ROPE) {
+                    // prefix tokens are not rotated (cos = 1, sin = 0 below); their loads read table row 0 and are discarded
+                    const int tb = max(tw[j] - FPREFIX, 0) * FHD + r;
+                    cc0[j] = cosv[tb];
+                    cc1[j] = cosv[tb + 32];
+                    ss0[j] = sinv[tb];
+                    ss1[j] = sinv[tb + 32];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = e0 + j, off = mt * 32 + crow(e, h), tr = t0 + off;
+                // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
+                const float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
+                float o0 = v0, o1 = v1;
+                if (ROPE) {
+                    const bool rot = tw[j] >= FPREFIX;
+                    const float c0 = rot ? cc0[j] : 1.0f, c1 = rot ? cc1[j] : 1.0f, s0 = rot ? ss0[j] : 0.0f, s1 = rot ? ss1[j] : 0.0f;
+                    o0 = v0 * c0 - v1 * s0;
+                    o1 = v1 * c1 + v0 * s1;
+                }
+                float *o = base + (long long)(tr + (tr >= T ? 5 * T : 0)) * FHD;
+                if (FULL || m0 + off < M) {
+                    o[0] = o0;
+                    o[32] = o1;
+                }
+            }
+        }
+    }
+    // images below 128 x 128 (T < 64: a tile spans several frames): (frame, token) by division per row, everything predicated
+    __device__ __forceinline__ void run_small(const f32x16 (&acc)[2][2], int which, long long m0, int n0, int r, int h, long long M) const {
+        const int head = (n0 % FD) / FHD;
         float *dst = which == 0 ? q : (which == 1 ? k : v);
         const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
 #pragma unroll
-        for (int me = 0; me < 4; me++) {            // 8 rows at a time: bounded temporaries (three workgroups per CU by registers)
-            const int mt = me >> 1, e0 = 8 * (me & 1);
-            float c0[8], c1[8], s0[8], s1[8];
-            unsigned fr[8], tk[8];
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int e = e0 + j;
-                const unsigned row = min((unsigned)(m0 + mt * 32 + crow(e, h)), (unsigned)(M - 1));
-                fr[j] = row / (unsigned)T;
-                tk[j] = row - fr[j] * T;
-                // prefix tokens (and v) are not rotated: cos = 1, sin = 0 (table row 0 is read and discarded)
-                const bool rot = which < 2 && tk[j] >= FPREFIX;
-                const long long tb = (long long)(rot ? tk[j] - FPREFIX : 0) * FHD;
-                const float cc0 = cosv[tb + r], cc1 = cosv[tb + 32 + r], ss0 = sinv[tb + r], ss1 = sinv[tb + 32 + r];
-                c0[j] = rot ? cc0 : 1.0f;
-                c1[j] = rot ? cc1 : 1.0f;
-                s0[j] = rot ? ss0 : 0.0f;
-                s1[j] = rot ? ss1 : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int e = e0 + j;
-                // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
-                const float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
-                float *o = dst + (((long long)fr[j] * FH + head) * T + tk[j]) * FHD;
-                if (m0 + mt * 32 + crow(e, h) < M) {
-                    o[r] = v0 * c0[j] - v1 * s0[j];
-                    o[32 + r] = v1 * c1[j] + v0 * s1[j];
+            for (int e = 0; e < 16; e++) {
+                const long long row = m0 + mt * 32 + crow(e, h);
+                if (row >= M) continue;
+                const long long f = row / T;
+                const int t = (int)(row - f * T);
+                float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
+                if (which < 2 && t >= FPREFIX) {
+                    const float *c = cosv + (long long)(t - FPREFIX) * FHD, *sn = sinv + (long long)(t - FPREFIX) * FHD;
+                    const float o0 = v0 * c[r] - v1 * sn[r], o1 = v1 * c[32 + r] + v0 * sn[32 + r];
+                    v0 = o0;
+                    v1 = o1;
                 }
+                float *o = dst + ((f * FH + head) * T + t) * FHD;
+                o[r] = v0;
+                o[32 + r] = v1;
             }
+    }
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        const int which = n0 / FD;                    // a wave's 64 columns are exactly one head of q, k or v: uniform branches
+        if (T < 64) {
+            run_small(acc, which, m0, n0, r, h, M);
+            return;
+        }
+        const bool full = m0 + 64 <= M;
+        if (which == 2) {
+            if (full) run<false, true>(acc, v, m0, n0, r, h, M); else run<false, false>(acc, v, m0, n0, r, h, M);
+        } else {
+            float *dst = which == 0 ? q : k;
+            if (full) run<true, true>(acc, dst, m0, n0, r, h, M); else run<true, false>(acc, dst, m0, n0, r, h, M);
         }
     }
 };
@@ -130,24 +182,42 @@ struct EpiResidual {          // x += ls * (acc + bias)
         }
     }
 };
+// erf(x), branch-free: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute (fp32 erff: ~1e-7) - the library erff is two
+// polynomial ranges behind a divergent branch, ~45 instructions and two exec-masked regions per value, 64 values per lane
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float p = 1.061405429f;
+    p = __builtin_fmaf(p, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);      // exp(-x^2)
+    const float y = __builtin_fmaf(-p * t, e, 1.0f);
+    return __builtin_copysignf(y, x);
+}
 struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch F.gelu default); columns stored in KP8 order (a GEMM's A operand)
     const float *b;
     float *hid;
-    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+    template <bool FULL>
+    __device__ __forceinline__ void run(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const float bv = b[n0 + nt * 32 + r];
-            const int col = kp8(n0 + nt * 32 + r);
+            float *col = hid + m0 * FMLP + kp8(n0 + nt * 32 + r);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const long long row = m0 + mt * 32 + crow(e, h);
+                    const int off = mt * 32 + crow(e, h);
                     const float v = acc[mt][nt][e] + bv;
-                    const float gl = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                    if (row < M) hid[row * FMLP + col] = gl;
+                    const float gl = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f));
+                    if (FULL || m0 + off < M) col[(long long)off * FMLP] = gl;
                 }
         }
+    }
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        if (m0 + 64 <= M) run<true>(acc, m0, n0, r, h, M); else run<false>(acc, m0, n0, r, h, M);     // uniform per wave
     }
 };
 
@@ -239,118 +309,125 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
 
 
 // ------------------------------------------------------------------------------------------ GEMM, per-layer form
-// The four GEMMs of a layer (96 % of the GEMM work).  Beside fp32 MFMAs every other vector instruction costs matrix time
-// (fp32 matrix time and vector time of a SIMD add up), so this form is written for instruction COUNT:
-//   * W is PRE-PACKED in MFMA fragment order (sslam_vit_f32_pack_linear_host): a wave fetches the B fragments of its two
-//     column tiles straight from L2 - one 1 KB buffer load per (tile, group of 8 k) with a SCALAR offset, ring of four groups -
-//     no LDS staging, no LDS reads, no address arithmetic for W;
-//   * A's producers (LayerNorm, attention, the GELU epilogue) write their columns in KP8 order, so the A tile goes global ->
-//     registers -> LDS as it is (no shuffle) and is read back with one ds_read_b128 per four MFMA steps; two LDS buffers, one
-//     barrier per k tile, the tile of step t + 1 is stored in front of the MFMAs of step t and the loads of t + 2 follow it.
-// Per k tile and wave: 64 MFMAs beside 8 + 4 loads, 4 LDS stores, 8 LDS reads (the generic form above: ~150 instructions).
+// The four GEMMs of a layer (96 % of the GEMM work): no LDS, no barrier, every wave on its own.
+//   * W is PRE-PACKED in MFMA fragment order (sslam_vit_f32_pack_linear_host): one 1 KB buffer load per (column tile, group of 8 k)
+//     with a SCALAR offset, straight from L2;
+//   * A's producers (LayerNorm, attention, the GELU epilogue) write their columns in KP8 order, so lane (r, h)'s four MFMA steps of
+//     a group are 16 contiguous bytes of ITS row: the A fragment is one buffer load per (row tile, group) too - 32 rows x 32 B per
+//     instruction; the two waves that share the rows hit in L1, the lines are used up over the four groups of a k tile;
+//   * ring of four groups (16 registers each): three groups = 3 072 matrix cycles of latency cover for the A rows (MALL / HBM).
+// Per group and wave: 16 MFMAs beside 4 loads and nothing else.
+// Three forms of this kernel were built and clock-probed (tools/vit_f32_probe.py): LDS-staged with two barriers per k tile (the
+// generic kernel above), LDS-staged A + streamed B with a third of its instructions, and this one.  All three run at the same
+// rate (QKV 0.65, up 0.72, down 0.78 of the nominal peak): a workgroup lives ~190 k cycles for 147 k of matrix time in the K = 384
+// GEMMs, whatever the loop looks like - the k loop itself is within 6 % of the matrix time (13.0 k cycles per k tile against
+// 12.3 k), what is left is (i) the epilogue of a 12-step GEMM: ~1 000 vector instructions that issue at about one per
+// co-resident MFMA (50-70 k cycles), only partly covered by the two other workgroups of the CU, and (ii) the clock the chip
+// holds in these kernels, 2.1 GHz (138 TFLOP/s) against 2.27 in a bare MFMA loop.  This form is kept because it is the simplest.
+#ifdef SSLAM_CLOCK_PROBE
+// probe builds only (tools/vit_f32_probe.py): wave 0 of the first 8192 workgroups stamps start / loop entry / loop exit / end
+__device__ unsigned long long g_probe_gemm_f32[4 * 8192];
+__device__ int g_probe_gemm_sel[2];        // (K, column tiles) of the GEMM to stamp
+#endif
 template <class Epi>
 __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
                                                                 long long M, int ntn, Epi epi) {
-    // + 1 152 floats of padding per buffer: 46 KB per workgroup = exactly THREE workgroups per CU whatever an instantiation's
-    // register count allows - the host sizes its launch groups in whole rounds of 3 x 256 workgroups (HipViTF32.chunk_frames)
-    __shared__ __attribute__((aligned(16))) float As[2][GBM * GLDK + 1152];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform BY CONSTRUCTION: the B loads' scalar offsets depend on it
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef SSLAM_CLOCK_PROBE
+    const unsigned long long pr_t0 = clock64();
+#endif
     // XCD-aware order: workgroup b runs on XCD b % 8, and the ntn workgroups that share an A tile (one row tile, all column tiles)
-    // must share an L2 - dealt out in natural order they land on eight different XCDs and the tile is fetched from HBM eight
-    // times (PMC: 0.9-1.1 GB read per launch against 0.1 GB of A).  Row tile = x + 8 (j / ntn), column tile = j % ntn for b = 8 j + x.
+    // share an L2: row tile = x + 8 (j / ntn), column tile = j % ntn for b = 8 j + x
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
     const long long m0 = (long long)(bx + 8 * (bj / ntn)) * GBM;
     if (m0 >= M) return;
     const int n0 = (bj % ntn) * GBN;
-    // A staging: thread = (row tid / 2, half tid % 2) moves 16 consecutive (already KP8-ordered) floats of its row per k tile
-    const int srow = tid >> 1, sh = tid & 1;
-    long long ar = m0 + srow;
-    if (ar > M - 1) ar = M - 1;
-    const float *ap = A + ar * lda + 16 * sh;
-    constexpr int ABUF = GBM * GLDK + 1152;
-    float *as_w = &As[0][srow * GLDK + 16 * sh];
-    float4 pa0, pa1, pa2, pa3;
-    auto fetch = [&](int k0) {
-        const float4 *src = reinterpret_cast<const float4 *>(ap + k0);
-        pa0 = src[0];
-        pa1 = src[1];
-        pa2 = src[2];
-        pa3 = src[3];
-    };
-    auto stash = [&](int buf) {
-        float4 *dst = reinterpret_cast<float4 *>(as_w + buf * ABUF);
-        dst[0] = pa0;
-        dst[1] = pa1;
-        dst[2] = pa2;
-        dst[3] = pa3;
-    };
-    // B fragments: packed W, fragment (column tile nt, group g) at ((nt * K / 8 + g) * 1024) bytes, lane * 16 inside it
     const int groups = K / 8;
+    // A fragments: rows clamped to M - 1 (the epilogue masks them); byte offset of lane (r, h) in group g: row * lda * 4 + 32 g + 16 h
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0xfffffffe, 0x00020000);
+    long long ra = m0 + wm * 64 + r, rb2 = ra + 32;
+    if (ra > M - 1) ra = M - 1;
+    if (rb2 > M - 1) rb2 = M - 1;
+    const unsigned ao0 = (unsigned)(ra * lda * 4 + 16 * h), ao1 = (unsigned)(rb2 * lda * 4 + 16 * h);
+    // B fragments: packed W, fragment (column tile nt, group g) at ((nt * K / 8 + g) * 1024) bytes, lane * 16 inside it
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, 0x7fffffff, 0x00020000);
     const int nt0 = (n0 + wn * 64) / 32;
     const int wo0 = nt0 * groups * 1024, wo1 = wo0 + groups * 1024, loff = lane * 16;
-    // ring of four groups (= one k tile), as named registers with compile-time slots (an indexed array ends up in scratch); three
-    // groups in flight.  Vector-memory operations return IN ORDER: a wait for a B fragment also waits for every load issued before
-    // it, so the A tile's loads (the long ones: HBM / MALL) go out right BEHIND the B loads of group 0 - the first B wait that
-    // can see them is three groups (3 072 matrix cycles) later.  (With the A loads at the head of the step and two groups in
-    // flight every step stalled on them: slower than the generic kernel despite a third of its instructions.)
-    f32x4 q00, q01, q10, q11, q20, q21, q30, q31;
-    auto loadb = [&](f32x4 &d0, f32x4 &d1, int G) {
-        d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
-        d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
+    struct Frag {
+        f32x4 a0, a1, b0, b1;
+    };
+    Frag q0, q1, q2, q3;
+    auto load = [&](Frag &d, int G) {
+        d.a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao0, G * 32, 0));
+        d.a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao1, G * 32, 0));
+        d.b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
+        d.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
     };
     f32x16 acc[2][2];
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0.0f;
-    const int n_kt = K / GBK;
-    fetch(0);
-    loadb(q00, q01, 0);
-    loadb(q10, q11, 1);
-    loadb(q20, q21, 2);
-    stash(0);
-    fetch(min(1, n_kt - 1) * GBK);
-    __syncthreads();
-    const float *Ar = &As[0][(wm * 64 + r) * GLDK + 4 * h];
-    // one group of 8 k: 2 LDS reads, 16 MFMAs on the B fragments c0 / c1
-    auto mma = [&](const float *Ab, int g, const f32x4 &c0, const f32x4 &c1) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + 8 * g), a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * GLDK + 8 * g);
+    load(q0, 0);
+    load(q1, 1);
+    load(q2, 2);
+#ifdef SSLAM_CLOCK_PROBE
+    const unsigned long long pr_t1 = clock64();
+#endif
+    auto mma = [&](const Frag &c) {
 #pragma unroll
         for (int st = 0; st < 4; st++) {
-            acc[0][0] = mfma32(a0[st], c0[st], acc[0][0]);
-            acc[0][1] = mfma32(a0[st], c1[st], acc[0][1]);
-            acc[1][0] = mfma32(a1[st], c0[st], acc[1][0]);
-            acc[1][1] = mfma32(a1[st], c1[st], acc[1][1]);
+            acc[0][0] = mfma32(c.a0[st], c.b0[st], acc[0][0]);
+            acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
+            acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
+            acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
         }
     };
 #pragma unroll 1
-    for (int kt = 0; kt < n_kt; kt++) {
-        const int buf = kt & 1, G = kt * 4;
-        const float *Ab = Ar + buf * ABUF;
-        // the tile of the NEXT step goes into the other buffer (read last in the previous step, behind its barrier)
-        stash(buf ^ 1);
-        loadb(q30, q31, min(G + 3, groups - 1));
-        fetch(min(kt + 2, n_kt - 1) * GBK);
+    for (int G = 0; G < groups; G += 4) {            // unconditional (clamped) loads: the compiler keeps an exact count in flight
+        load(q3, min(G + 3, groups - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mma(Ab, 0, q00, q01);
+        mma(q0);
         __builtin_amdgcn_sched_barrier(0);
-        loadb(q00, q01, min(G + 4, groups - 1));
+        load(q0, min(G + 4, groups - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mma(Ab, 1, q10, q11);
+        mma(q1);
         __builtin_amdgcn_sched_barrier(0);
-        loadb(q10, q11, min(G + 5, groups - 1));
+        load(q1, min(G + 5, groups - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mma(Ab, 2, q20, q21);
+        mma(q2);
         __builtin_amdgcn_sched_barrier(0);
-        loadb(q20, q21, min(G + 6, groups - 1));
+        load(q2, min(G + 6, groups - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mma(Ab, 3, q30, q31);
+        mma(q3);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
     }
+#ifdef SSLAM_CLOCK_PROBE
+    const unsigned long long pr_t2 = clock64();
+#endif
     epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
+#ifdef SSLAM_CLOCK_PROBE
+    if (tid == 0 && blockIdx.x < 8192 && K == g_probe_gemm_sel[0] && ntn == g_probe_gemm_sel[1]) {
+        unsigned long long *o_ = g_probe_gemm_f32 + 4 * blockIdx.x;
+        o_[0] = pr_t1 - pr_t0;
+        o_[1] = pr_t2 - pr_t1;
+        o_[2] = clock64() - pr_t2;
+        o_[3] = pr_t0;
+    }
+#endif
 }
+
+#ifdef SSLAM_CLOCK_PROBE
+extern "C" int sslam_probe_gemm_f32_select(int K, int ntn) {
+    const int v[2] = {K, ntn};
+    unsigned long long *p = nullptr;
+    if (hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_probe_gemm_f32)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 4 * 8192);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe_gemm_sel), v, sizeof(v)) == hipSuccess ? 0 : -3;
+}
+extern "C" int sslam_probe_gemm_f32(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe_gemm_f32), sizeof(unsigned long long) * 4 * 8192) == hipSuccess ? 0 : -3;
+}
+#endif
 
 template <class Epi>
 int launch_gemm_rows(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
