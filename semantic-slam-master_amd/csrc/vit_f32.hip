@@ -323,7 +323,8 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
 // GEMMs, whatever the loop looks like - the k loop itself is within 6 % of the matrix time (13.0 k cycles per k tile against
 // 12.3 k), what is left is (i) the epilogue of a 12-step GEMM: ~1 000 vector instructions that issue at about one per
 // co-resident MFMA (50-70 k cycles), only partly covered by the two other workgroups of the CU, and (ii) the clock the chip
-// holds in these kernels, 2.1 GHz (138 TFLOP/s) against 2.27 in a bare MFMA loop.  This form is kept because it is the simplest.
+// holds in these kernels, 2.1 GHz (138 TFLOP/s) against 2.27 in a bare MFMA loop.  Raising the issue priority of the epilogue
+// (s_setprio 3) changes neither its length nor the kernel's.  This form is kept because it is the simplest.
 #ifdef SSLAM_CLOCK_PROBE
 // probe builds only (tools/vit_f32_probe.py): wave 0 of the first 8192 workgroups stamps start / loop entry / loop exit / end
 __device__ unsigned long long g_probe_gemm_f32[4 * 8192];
