@@ -228,6 +228,22 @@ def test_vit_f32_weight_pack_is_a_permutation_in_fragment_order():
         lib.pack_vit_f32_linear(np.zeros((128, 48), np.float32))
 
 
+def test_fp32_vit_launch_groups_are_whole_rounds_of_workgroups():
+    """HipViTF32.chunk_frames: the per-layer GEMMs run one workgroup per (128-row tile, 128 columns) at three per CU - the launch
+    group is the largest frame count whose row tiles (padded to the 8 XCDs) fill whole rounds of 768 workgroups for N = 384, 1152
+    and 1536 alike (64 frames left the N = 384 GEMMs at 1.54 rounds)."""
+    from sslam_amd.vit_hip import HipViTF32
+    for size, want in ((448, 83), (640, 40), (960, 18)):
+        n = HipViTF32.chunk_frames(size)
+        assert n == want
+        t = 5 + (size // 16) ** 2
+        tiles = -(-(n * t) // 128)
+        assert tiles <= 512 < -(-((n + 1) * t) // 128)              # the largest frame count within 512 row tiles
+        for cols in (3, 9, 12):
+            rounds = -(-tiles // 8) * 8 * cols / 768.0
+            assert rounds <= round(rounds) + 1e-9 and (round(rounds) - rounds) / round(rounds) < 0.05     # < 5 % of the launch idle
+
+
 def test_backbone_vit_precision_flag_and_device_guard():
     from models.dino_backbone import DinoBackbone
     from sslam_amd.vit import DinoV3ViT
