@@ -278,7 +278,7 @@ typedef struct {
     const float *norm_g, *norm_b, *rope_cos, *rope_sin;
 } sslam_vit_weights_f32_t;
 /* host helper: fp32 nn.Linear weight (n_out, k_in), n_out % 128 == 0, k_in % 32 == 0 -> element (n, k) at
- * [n/32][k/8][k%2][n%32][(k%8)/2] */
+ * [n/32][k/8][(k%8)/4][n%32][k%4] */
 int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_in, float *out);
 long long sslam_vit_f32_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *weights_host_struct,

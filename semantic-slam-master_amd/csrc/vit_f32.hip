@@ -62,101 +62,57 @@ struct EpiPatch {             // x[frame][5 + patch] = acc + bias
             }
     }
 };
-struct EpiQKV {               // + bias, RoPE on the patch tokens of q and k, scatter to (frame, head, token, 64)
+// ---- epilogues of the per-layer GEMM (gemm_f32_rows_kernel evaluates the product TRANSPOSED: weights = A operand) ---------------
+// acc layout there: register e of lane (r, h) in tile (ni, ri) is column n0 + 32 ni + crow(e, h) of row m0 + 32 ri + r - a lane owns
+// a ROW and holds four consecutive columns per group of four registers, so everything it loads or stores is 16 bytes wide
+// (dword stores cost ~6 x the time per byte of dwordx4 stores: the first form's 64 dword stores per lane made the epilogue of a
+// 12-step GEMM as long as a third of its k loop).
+struct TQKV {                 // + bias, RoPE on the patch tokens of q and k, scatter to (frame, head, token, 64)
+    static constexpr bool TRANSPOSED = true;
     const float *b, *cosv, *sinv;
     float *q, *k, *v;
     int T;
-    // FULL: every row of the wave's 64 x 64 tile is inside M (all tiles but the last row tile): stores need no predicate.
-    // Requires T >= 64 (a tile of 64 rows crosses at most one frame boundary); smaller token counts take run_small.
-    template <bool ROPE, bool FULL>
-    __device__ __forceinline__ void run(const f32x16 (&acc)[2][2], float *dst, long long m0, int n0, int r, int h, long long M) const {
-        const int head = (n0 % FD) / FHD;
-        const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
-        // (frame, token) of the wave's first row by ONE division; the 64 rows that follow are reached by adding (T > 64: at most one
-        // frame boundary inside the tile) - 32 integer divisions per lane cost more than the tile's arithmetic.  Destination row of
-        // token index tr = t0 + offset (not wrapped): (f0 * 6 + head) * T + tr, plus 5 T once tr has passed into the next frame
-        const unsigned f0 = (unsigned)(m0 / T);
-        const int t0 = (int)(m0 - (long long)f0 * T);
-        float *base = dst + ((long long)f0 * FH + head) * T * FHD + r;
-#pragma unroll
-        for (int blk = 0; blk < 8; blk++) {           // 4 rows at a time: their 16 table values are requested together, then used
-            const int mt = blk >> 2, e0 = 4 * (blk & 3);
-            float cc0[4], cc1[4], ss0[4], ss1[4];
-            int tw[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int tr = t0 + mt * 32 + crow(e0 + j, h);
-                tw[j] = tr >= T ? tr - T : tr;
-                if (ROPE) {
-                    // prefix tokens are not rotated (cos = 1, sin = 0 below); their loads read table row 0 and are discarded
-                    const int tb = max(tw[j] - FPREFIX, 0) * FHD + r;
-                    cc0[j] = cosv[tb];
-                    cc1[j] = cosv[tb + 32];
-                    ss0[j] = sinv[tb];
-                    ss1[j] = sinv[tb + 32];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int e = e0 + j, off = mt * 32 + crow(e, h), tr = t0 + off;
-                // rotate_half: out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
-                const float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
-                float o0 = v0, o1 = v1;
-                if (ROPE) {
-                    const bool rot = tw[j] >= FPREFIX;
-                    const float c0 = rot ? cc0[j] : 1.0f, c1 = rot ? cc1[j] : 1.0f, s0 = rot ? ss0[j] : 0.0f, s1 = rot ? ss1[j] : 0.0f;
-                    o0 = v0 * c0 - v1 * s0;
-                    o1 = v1 * c1 + v0 * s1;
-                }
-                float *o = base + (long long)(tr + (tr >= T ? 5 * T : 0)) * FHD;
-                if (FULL || m0 + off < M) {
-                    o[0] = o0;
-                    o[32] = o1;
-                }
-            }
-        }
-    }
-    // images below 128 x 128 (T < 64: a tile spans several frames): (frame, token) by division per row, everything predicated
-    __device__ __forceinline__ void run_small(const f32x16 (&acc)[2][2], int which, long long m0, int n0, int r, int h, long long M) const {
-        const int head = (n0 % FD) / FHD;
-        float *dst = which == 0 ? q : (which == 1 ? k : v);
-        const float b0 = b[n0 + r], b1 = b[n0 + 32 + r];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const long long row = m0 + mt * 32 + crow(e, h);
-                if (row >= M) continue;
-                const long long f = row / T;
-                const int t = (int)(row - f * T);
-                float v0 = acc[mt][0][e] + b0, v1 = acc[mt][1][e] + b1;
-                if (which < 2 && t >= FPREFIX) {
-                    const float *c = cosv + (long long)(t - FPREFIX) * FHD, *sn = sinv + (long long)(t - FPREFIX) * FHD;
-                    const float o0 = v0 * c[r] - v1 * sn[r], o1 = v1 * c[32 + r] + v0 * sn[32 + r];
-                    v0 = o0;
-                    v1 = o1;
-                }
-                float *o = dst + ((f * FH + head) * T + t) * FHD;
-                o[r] = v0;
-                o[32 + r] = v1;
-            }
-    }
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
-        const int which = n0 / FD;                    // a wave's 64 columns are exactly one head of q, k or v: uniform branches
-        if (T < 64) {
-            run_small(acc, which, m0, n0, r, h, M);
-            return;
-        }
-        const bool full = m0 + 64 <= M;
-        if (which == 2) {
-            if (full) run<false, true>(acc, v, m0, n0, r, h, M); else run<false, false>(acc, v, m0, n0, r, h, M);
-        } else {
-            float *dst = which == 0 ? q : k;
-            if (full) run<true, true>(acc, dst, m0, n0, r, h, M); else run<true, false>(acc, dst, m0, n0, r, h, M);
+        const int which = n0 / FD, head = (n0 % FD) / FHD;            // a wave's 64 columns are exactly one head of q, k or v
+        float *dst = which == 0 ? q : (which == 1 ? k : v);
+        const bool rope = which < 2;
+#pragma unroll
+        for (int ri = 0; ri < 2; ri++) {
+            const long long row = m0 + 32 * ri + r;
+            if (row >= M) continue;
+            const long long f = row / T;
+            const int t = (int)(row - f * T);
+            const bool rot = rope && t >= FPREFIX;                   // prefix tokens (and v) are not rotated
+            const float *ct = cosv + (long long)(rot ? t - FPREFIX : 0) * FHD + 4 * h, *st = sinv + (long long)(rot ? t - FPREFIX : 0) * FHD + 4 * h;
+            float *o = dst + ((f * FH + head) * T + t) * FHD + 4 * h;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                // d = 8 qd + 4 h + i in the first half of the head (tile ni = 0), d + 32 in the second (ni = 1): rotate_half pairs them
+                const float4 b0 = *reinterpret_cast<const float4 *>(b + n0 + 8 * qd + 4 * h), b1 = *reinterpret_cast<const float4 *>(b + n0 + 32 + 8 * qd + 4 * h);
+                float4 c0 = make_float4(1.f, 1.f, 1.f, 1.f), c1 = c0, s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+                if (rot) {
+                    c0 = *reinterpret_cast<const float4 *>(ct + 8 * qd);
+                    c1 = *reinterpret_cast<const float4 *>(ct + 32 + 8 * qd);
+                    s0 = *reinterpret_cast<const float4 *>(st + 8 * qd);
+                    s1 = *reinterpret_cast<const float4 *>(st + 32 + 8 * qd);
+                }
+                const float v0x = acc[0][ri][4 * qd] + b0.x, v0y = acc[0][ri][4 * qd + 1] + b0.y, v0z = acc[0][ri][4 * qd + 2] + b0.z, v0w = acc[0][ri][4 * qd + 3] + b0.w;
+                const float v1x = acc[1][ri][4 * qd] + b1.x, v1y = acc[1][ri][4 * qd + 1] + b1.y, v1z = acc[1][ri][4 * qd + 2] + b1.z, v1w = acc[1][ri][4 * qd + 3] + b1.w;
+                // out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)
+                const float4 o0 = make_float4(v0x * c0.x - v1x * s0.x, v0y * c0.y - v1y * s0.y, v0z * c0.z - v1z * s0.z, v0w * c0.w - v1w * s0.w);
+                const float4 o1 = make_float4(v1x * c1.x + v0x * s1.x, v1y * c1.y + v0y * s1.y, v1z * c1.z + v0z * s1.z, v1w * c1.w + v0w * s1.w);
+                *reinterpret_cast<float4 *>(o + 8 * qd) = o0;
+                *reinterpret_cast<float4 *>(o + 32 + 8 * qd) = o1;
+            }
         }
     }
 };
+// The residual epilogue is a read-modify-write of x: with a row per lane every 16-byte access touches 32 different 128-byte lines
+// (measured: 36 -> 69 k cycles for o_proj, 40 -> 141 k for the down projection), so these two GEMMs keep the product the other
+// way round - register e of lane (r, h) in tile (mt, nt) is row 32 mt + crow(e, h), column 32 nt + r: dword accesses, but each
+// instruction covers two whole 128-byte lines.
 struct EpiResidual {          // x += ls * (acc + bias)
+    static constexpr bool TRANSPOSED = false;
     const float *b, *ls;
     float *x;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
@@ -196,28 +152,30 @@ __device__ __forceinline__ float erf_as(float x) {
     const float y = __builtin_fmaf(-p * t, e, 1.0f);
     return __builtin_copysignf(y, x);
 }
-struct EpiGelu {              // hidden = gelu(acc + bias), the erf form (torch F.gelu default); columns stored in KP8 order (a GEMM's A operand)
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f)); }
+struct TGelu {                // hidden = gelu(acc + bias), the erf form (torch F.gelu default)
+    static constexpr bool TRANSPOSED = true;
     const float *b;
     float *hid;
-    template <bool FULL>
-    __device__ __forceinline__ void run(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const float bv = b[n0 + nt * 32 + r];
-            float *col = hid + m0 * FMLP + kp8(n0 + nt * 32 + r);
+        for (int ri = 0; ri < 2; ri++) {
+            const long long row = m0 + 32 * ri + r;
+            if (row >= M) continue;
+            float *hr = hid + row * FMLP + n0 + 4 * h;
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int off = mt * 32 + crow(e, h);
-                    const float v = acc[mt][nt][e] + bv;
-                    const float gl = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f));
-                    if (FULL || m0 + off < M) col[(long long)off * FMLP] = gl;
+                for (int qd = 0; qd < 4; qd++) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(b + n0 + 32 * ni + 8 * qd + 4 * h);
+                    float4 o;
+                    o.x = gelu_erf(acc[ni][ri][4 * qd] + bv.x);
+                    o.y = gelu_erf(acc[ni][ri][4 * qd + 1] + bv.y);
+                    o.z = gelu_erf(acc[ni][ri][4 * qd + 2] + bv.z);
+                    o.w = gelu_erf(acc[ni][ri][4 * qd + 3] + bv.w);
+                    *reinterpret_cast<float4 *>(hr + 32 * ni + 8 * qd) = o;
                 }
         }
-    }
-    __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
-        if (m0 + 64 <= M) run<true>(acc, m0, n0, r, h, M); else run<false>(acc, m0, n0, r, h, M);     // uniform per wave
     }
 };
 
@@ -312,9 +270,11 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
 // The four GEMMs of a layer (96 % of the GEMM work): no LDS, no barrier, every wave on its own.
 //   * W is PRE-PACKED in MFMA fragment order (sslam_vit_f32_pack_linear_host): one 1 KB buffer load per (column tile, group of 8 k)
 //     with a SCALAR offset, straight from L2;
-//   * A's producers (LayerNorm, attention, the GELU epilogue) write their columns in KP8 order, so lane (r, h)'s four MFMA steps of
-//     a group are 16 contiguous bytes of ITS row: the A fragment is one buffer load per (row tile, group) too - 32 rows x 32 B per
-//     instruction; the two waves that share the rows hit in L1, the lines are used up over the four groups of a k tile;
+//   * with the k order 8 g + 4 h + s (below) lane (r, h)'s four MFMA steps of a group are 16 contiguous bytes of ITS row in the
+//     natural layout: the A fragment is one buffer load per (row tile, group) too - 32 rows x 32 B per instruction; the two waves
+//     that share the rows hit in L1, the lines are used up over the four groups of a k tile;
+//   * the product is evaluated transposed (weights = MFMA A operand), so a lane owns a ROW of the output and every epilogue access
+//     is 16 bytes wide;
 //   * ring of four groups (16 registers each): three groups = 3 072 matrix cycles of latency cover for the A rows (MALL / HBM).
 // Per group and wave: 16 MFMAs beside 4 loads and nothing else.
 // Three forms of this kernel were built and clock-probed (tools/vit_f32_probe.py): LDS-staged with two barriers per k tile (the
@@ -346,6 +306,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     if (m0 >= M) return;
     const int n0 = (bj % ntn) * GBN;
     const int groups = K / 8;
+    // k order inside a group of 8: MFMA step s multiplies k = 8 g + s (lanes h = 0) and 8 g + 4 + s (h = 1) - any pairing of the
+    // two lane halves is a valid k order as long as both operands use it, and with this one a lane's four steps are 16 CONTIGUOUS
+    // bytes of its row in the natural layout (the KP8 order of the exact kernels, k = 8 g + 2 s + h, pins the fma chain to
+    // increasing k; nothing here needs that).
     // A fragments: rows clamped to M - 1 (the epilogue masks them); byte offset of lane (r, h) in group g: row * lda * 4 + 32 g + 16 h
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0xfffffffe, 0x00020000);
     long long ra = m0 + wm * 64 + r, rb2 = ra + 32;
@@ -375,13 +339,23 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
 #ifdef SSLAM_CLOCK_PROBE
     const unsigned long long pr_t1 = clock64();
 #endif
+    // TRANSPOSED product: weights are the MFMA's A operand, activation rows its B operand - acc[ni][ri] register e of lane (r, h) is
+    // column 32 ni + crow(e, h), row 32 ri + r: a lane owns a row, four consecutive columns per four registers (16-byte epilogues)
+    // (Epi::TRANSPOSED = false, the residual epilogues: rows on the registers, columns on the lanes)
     auto mma = [&](const Frag &c) {
 #pragma unroll
         for (int st = 0; st < 4; st++) {
-            acc[0][0] = mfma32(c.a0[st], c.b0[st], acc[0][0]);
-            acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
-            acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
-            acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
+            if (Epi::TRANSPOSED) {
+                acc[0][0] = mfma32(c.b0[st], c.a0[st], acc[0][0]);
+                acc[0][1] = mfma32(c.b0[st], c.a1[st], acc[0][1]);
+                acc[1][0] = mfma32(c.b1[st], c.a0[st], acc[1][0]);
+                acc[1][1] = mfma32(c.b1[st], c.a1[st], acc[1][1]);
+            } else {
+                acc[0][0] = mfma32(c.a0[st], c.b0[st], acc[0][0]);
+                acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
+                acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
+                acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
+            }
         }
     };
 #pragma unroll 1
@@ -440,9 +414,7 @@ int launch_gemm_rows(const float *A, int lda, const float *Wp, int K, long long 
 }
 
 // ------------------------------------------------------------------------------------------------------ LayerNorm
-// two-pass, one wave per row of 384 (torch.nn.LayerNorm: biased variance, eps inside the square root).  PERM: the columns are
-// written in KP8 order (position of column c inside its group of 8: (0,2,4,6,1,3,5,7)) - the layout gemm_f32_rows_kernel reads
-template <bool PERM>
+// two-pass, one wave per row of 384 (torch.nn.LayerNorm: biased variance, eps inside the square root)
 __global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
                                                            float eps, long long rows, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -469,12 +441,7 @@ __global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float *__restric
         float2 o;
         o.x = (v[2 * j] - mean) * rstd * g[c] + b[c];
         o.y = (v[2 * j + 1] - mean) * rstd * g[c + 1] + b[c + 1];
-        if (PERM) {
-            out[row * FD + kp8(c)] = o.x;
-            out[row * FD + kp8(c + 1)] = o.y;
-        } else {
-            *reinterpret_cast<float2 *>(out + row * FD + c) = o;
-        }
+        *reinterpret_cast<float2 *>(out + row * FD + c) = o;
     }
 }
 
@@ -599,21 +566,18 @@ __global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__res
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const int frame = bh / FH, head = bh % FH;
-    float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 2 * h;
-    // register e of o[dt] is O[query r][d = 32 dt + 8 g + 4 h + i], e = 4 g + i.  y is the A operand of the o_proj GEMM: columns in
-    // KP8 order, i.e. inside the group of 8 the even d at positions 0..3 and the odd d at 4..7 - this lane's d = 4 h + {0, 2} go to
-    // positions 2 h, 2 h + 1 and d = 4 h + {1, 3} to 4 + 2 h, 5 + 2 h: two 8-byte stores per group
+    float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 4 * h;
+    // register e of o[dt] is O[query r][32 dt + crow(e, h)]: four consecutive d per group of four registers
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            float2 ev, od;
-            ev.x = o[dt][4 * g] * inv;
-            ev.y = o[dt][4 * g + 2] * inv;
-            od.x = o[dt][4 * g + 1] * inv;
-            od.y = o[dt][4 * g + 3] * inv;
-            *reinterpret_cast<float2 *>(dst + 32 * dt + 8 * g) = ev;
-            *reinterpret_cast<float2 *>(dst + 32 * dt + 8 * g + 4) = od;
+            float4 t;
+            t.x = o[dt][4 * g] * inv;
+            t.y = o[dt][4 * g + 1] * inv;
+            t.z = o[dt][4 * g + 2] * inv;
+            t.w = o[dt][4 * g + 3] * inv;
+            *reinterpret_cast<float4 *>(dst + 32 * dt + 8 * g) = t;
         }
 }
 
@@ -622,13 +586,13 @@ inline size_t ws_align(long long b) { return ((size_t)b + 255) & ~(size_t)255; }
 }  // namespace
 
 // nn.Linear weight (n_out, k_in) fp32 -> the fragment order gemm_f32_rows_kernel streams: out[nt][g][h][r][s] =
-// w[32 nt + r][8 g + 2 s + h] (one 1 KB fragment per 32 columns x 8 k: lane (r, h) reads its four MFMA steps as one float4)
+// w[32 nt + r][8 g + 4 h + s] (one 1 KB fragment per 32 columns x 8 k: lane (r, h) reads its four MFMA steps as one float4)
 extern "C" int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_in, float *out) {
     if (!w || !out || n_out <= 0 || k_in <= 0 || n_out % GBN || k_in % GBK) return SSLAM_E_INVALID;
     const int groups = k_in / 8;
     for (int n = 0; n < n_out; n++)
         for (int k = 0; k < k_in; k++) {
-            const int nt = n / 32, r = n % 32, g = k / 8, s2 = (k % 8) / 2, h = k % 2;
+            const int nt = n / 32, r = n % 32, g = k / 8, h = (k % 8) / 4, s2 = k % 4;
             out[((((long long)nt * groups + g) * 2 + h) * 32 + r) * 4 + s2] = w[(long long)n * k_in + k];
         }
     return SSLAM_OK;
@@ -662,18 +626,18 @@ extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int 
     const int n_qt = (T + 31) / 32, subs = (n_qt + AW - 1) / AW, nbh = n_frames * FH;
     for (int L = 0; L < FLAYERS; L++) {
         const sslam_vit_layer_f32_t &ly = w->layer[L];
-        hipLaunchKernelGGL(ln_rows_f32_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
+        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
         sslam_count_launches(1);
-        if ((rc = launch_gemm_rows(y, FD, ly.wqkv, FD, rows, 3 * FD, EpiQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm_rows(y, FD, ly.wqkv, FD, rows, 3 * FD, TQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
         hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((nbh + 7) / 8 * 8 * subs)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs);
         sslam_count_launches(1);
         if ((rc = launch_gemm_rows(y, FD, ly.wo, FD, rows, FD, EpiResidual{ly.bo, ly.ls1, x}, st)) != SSLAM_OK) return rc;
-        hipLaunchKernelGGL(ln_rows_f32_kernel<true>, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
+        hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
         sslam_count_launches(1);
-        if ((rc = launch_gemm_rows(y, FD, ly.wup, FD, rows, FMLP, EpiGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
+        if ((rc = launch_gemm_rows(y, FD, ly.wup, FD, rows, FMLP, TGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
         if ((rc = launch_gemm_rows(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
     }
-    hipLaunchKernelGGL(ln_rows_f32_kernel<false>, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
+    hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
     SSLAM_CHECK_LAUNCH();
     return SSLAM_OK;
 }

@@ -213,14 +213,14 @@ def test_lib_rejects_cpu_and_mixed_device_arguments():
 
 def test_vit_f32_weight_pack_is_a_permutation_in_fragment_order():
     """sslam_vit_f32_pack_linear_host (host code, no GPU): element (n, k) of an nn.Linear weight lands at
-    [n/32][k/8][k%2][n%32][(k%8)/2] - every value exactly once; shapes the kernel cannot tile are refused."""
+    [n/32][k/8][(k%8)/4][n%32][k%4] - every value exactly once; shapes the kernel cannot tile are refused."""
     from sslam_amd import lib
     rng = np.random.default_rng(0)
     for n_out, k_in in ((1152, 384), (384, 1536), (128, 96)):
         w = rng.standard_normal((n_out, k_in)).astype(np.float32)
         p = lib.pack_vit_f32_linear(w).reshape(n_out // 32, k_in // 8, 2, 32, 4)
         n, k = rng.integers(0, n_out, 200), rng.integers(0, k_in, 200)
-        assert np.array_equal(p[n // 32, k // 8, k % 2, n % 32, (k % 8) // 2], w[n, k])
+        assert np.array_equal(p[n // 32, k // 8, (k % 8) // 4, n % 32, k % 4], w[n, k])
         assert np.array_equal(np.sort(p.ravel()), np.sort(w.ravel()))
     with pytest.raises(ValueError):
         lib.pack_vit_f32_linear(np.zeros((100, 96), np.float32))
