@@ -472,12 +472,13 @@ __global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__res
     const bool wave_on = qt < n_qt;                               // a wave without queries still helps staging
     const int qi = min(qt * 32 + r, T - 1);
     const float *qp = q + ((long long)bh * T + qi) * FHD, *kp = k + (long long)bh * T * FHD, *vp = v + (long long)bh * T * FHD;
+    constexpr float QS = 0.125f * 1.4426950408889634f;
     float qreg[32];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
-        qreg[2 * i] = (h ? t.y : t.x) * 0.125f;                   // 1 / sqrt(64): exact
-        qreg[2 * i + 1] = (h ? t.w : t.z) * 0.125f;
+        qreg[2 * i] = (h ? t.y : t.x) * QS;                       // 1 / sqrt(64) and log2(e): the softmax runs in the exp2 domain
+        qreg[2 * i + 1] = (h ? t.w : t.z) * QS;
     }
     // staging, 256 threads: K tile = 32 keys x 8 groups of 8 (one item per thread, KP8 image); V tile = 32 keys x 16 float4
     // (two per thread: keys tid / 16 and 16 + tid / 16)
@@ -531,17 +532,18 @@ __global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__res
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     if (kt * AKT + crow(e, h) >= T) s[e] = -INFINITY;
+                asm volatile("" ::: "memory");       // keeps this a branch (if-converted it is 17 selects in every tile)
             }
             float mx = m;
 #pragma unroll
             for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float alpha = __expf(m - mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mx);
             m = mx;
             float ps = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                s[e] = __expf(s[e] - mx);
+                s[e] = __builtin_amdgcn_exp2f(s[e] - mx);
                 ps += s[e];
             }
             l = l * alpha + ps;
