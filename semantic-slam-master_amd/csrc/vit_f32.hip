@@ -613,7 +613,9 @@ extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int 
     if (((uintptr_t)images_chw | (uintptr_t)workspace | (uintptr_t)tokens_out) & 15) return SSLAM_E_INVALID;
     const int G = size / FPATCH, cells = G * G, T = cells + FPREFIX;
     const long long rows = (long long)n_frames * T, prow = (long long)n_frames * cells;
-    if (rows * FMLP > 0x7fffffffLL * 16) return SSLAM_E_UNSUPPORTED;
+    // the per-layer GEMM addresses its A operand through one buffer descriptor with 32-bit byte offsets: the widest matrix (the MLP
+    // hidden activation, 6 KB per token) must stay below 4 GiB - 886 frames at 448 x 448; callers cut larger batches into launch groups
+    if (rows * FMLP * 4 > 0xfffffff0LL) return SSLAM_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     char *p = (char *)workspace;
     float *x = (float *)p;    p += ws_align(rows * FD * 4);
