@@ -455,11 +455,20 @@ __global__ __launch_bounds__(64) void prefix_rows_f32_kernel(const float *__rest
 
 // ------------------------------------------------------------------------------------------------------ attention
 // q, k, v (n * 6, T, 64) fp32 -> y (n, T, 384), softmax(q k^T / 8) v.  A wave owns 32 queries: its query rows live in 32
-// registers as the B operand of S^T = K Q^T (lane (r, h) holds q[r][2 s + h] of step s), so accumulator register e of lane
-// (r, h) is the score of key crow(e, h) against query r - running maximum and row sum are lane-local (+ one xor-32), and
+// registers as the B operand of S^T = K Q^T (lane (r, h) holds q[r][8 g + 4 h + s] for step 4 g + s), so accumulator register e
+// of lane (r, h) is the score of key crow(e, h) against query r - running maximum and row sum are lane-local (+ one xor-32), and
 // register e, exponentiated, is directly the B operand (keys crow(e, 0), crow(e, 1)) of step e of O^T = V^T P^T.
+//
+// The tile loop is software-pipelined INSIDE the wave (as the matcher's, match.hip): iteration kt multiplies S^T of tile kt + 1
+// and, behind every group of 4 of those MFMAs (256 cycles of matrix work), issues one slice of tile kt's softmax (and the LDS
+// reads of its V^T fragments); then O^T += V^T P^T of tile kt with the LDS stores of the prefetched tiles behind its MFMAs.
+// Run one after the other (multiply, softmax, multiply), two waves sharing a SIMD's matrix pipe fall into step - they multiply
+// together and then exponentiate together, and the pipe idles through every softmax: 0.77 of its cycles busy, 782 us per layer
+// and 83 frames.  sched_barrier pins the interleave (left alone, hipcc issues the MFMAs back to back).
+// K runs one tile ahead of V in LDS: iteration kt reads K(kt + 1) and V(kt), stores K(kt + 2) and V(kt + 1).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int AW = 4, AKT = 32, ALDK = 68;      // waves per workgroup (4 x 32 queries; one wave per SIMD and workgroup), keys per tile
-__global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+__global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                             float *__restrict__ y, int T, int nbh, int subs) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AKT * ALDK], Vs[2][AKT * FHD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -472,99 +481,186 @@ __global__ __launch_bounds__(64 * AW, 2) void attn_f32_kernel(const float *__res
     const bool wave_on = qt < n_qt;                               // a wave without queries still helps staging
     const int qi = min(qt * 32 + r, T - 1);
     const float *qp = q + ((long long)bh * T + qi) * FHD, *kp = k + (long long)bh * T * FHD, *vp = v + (long long)bh * T * FHD;
-    constexpr float QS = 0.125f * 1.4426950408889634f;
+    constexpr float QS = 0.125f * 1.4426950408889634f;           // 1 / sqrt(64) and log2(e): the softmax runs in the exp2 domain
     float qreg[32];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const float4 t = *reinterpret_cast<const float4 *>(qp + 4 * i);
-        qreg[2 * i] = (h ? t.y : t.x) * QS;                       // 1 / sqrt(64) and log2(e): the softmax runs in the exp2 domain
-        qreg[2 * i + 1] = (h ? t.w : t.z) * QS;
+    for (int g = 0; g < 8; g++) {
+        const float4 t = *reinterpret_cast<const float4 *>(qp + 8 * g + 4 * h);
+        qreg[4 * g] = t.x * QS;
+        qreg[4 * g + 1] = t.y * QS;
+        qreg[4 * g + 2] = t.z * QS;
+        qreg[4 * g + 3] = t.w * QS;
     }
-    // staging, 256 threads: K tile = 32 keys x 8 groups of 8 (one item per thread, KP8 image); V tile = 32 keys x 16 float4
-    // (two per thread: keys tid / 16 and 16 + tid / 16)
+    // staging, 256 threads: K tile = 32 keys x 16 float4 and V tile likewise, two float4 of each per thread (keys tid / 16 and
+    // 16 + tid / 16); rows beyond T re-read row T - 1 (masked in the last tile)
     float4 pk0, pk1, pv0, pv1;
-    const int skey = tid >> 3, sg = tid & 7, vkey = tid >> 4, vq = tid & 15;
-    auto fetch = [&](int key0) {
-        const float *src = kp + (long long)min(key0 + skey, T - 1) * FHD + 8 * sg;
-        pk0 = *reinterpret_cast<const float4 *>(src);
-        pk1 = *reinterpret_cast<const float4 *>(src + 4);
-        pv0 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + vkey, T - 1) * FHD + 4 * vq);
-        pv1 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + 16 + vkey, T - 1) * FHD + 4 * vq);
+    const int skey = tid >> 4, sq4 = tid & 15;
+    auto fetch_k = [&](int key0) {
+        pk0 = *reinterpret_cast<const float4 *>(kp + (long long)min(key0 + skey, T - 1) * FHD + 4 * sq4);
+        pk1 = *reinterpret_cast<const float4 *>(kp + (long long)min(key0 + 16 + skey, T - 1) * FHD + 4 * sq4);
     };
-    auto stash = [&](int buf) {
-        float4 ev, od;
-        kp8_split(pk0, pk1, ev, od);
-        *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg]) = ev;
-        *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 8 * sg + 4]) = od;
-        *reinterpret_cast<float4 *>(&Vs[buf][vkey * FHD + 4 * vq]) = pv0;
-        *reinterpret_cast<float4 *>(&Vs[buf][(16 + vkey) * FHD + 4 * vq]) = pv1;
+    auto fetch_v = [&](int key0) {
+        pv0 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + skey, T - 1) * FHD + 4 * sq4);
+        pv1 = *reinterpret_cast<const float4 *>(vp + (long long)min(key0 + 16 + skey, T - 1) * FHD + 4 * sq4);
     };
-    f32x16 o[2];
+    auto stash_k = [&](int buf) {
+        *reinterpret_cast<float4 *>(&Ks[buf][skey * ALDK + 4 * sq4]) = pk0;
+        *reinterpret_cast<float4 *>(&Ks[buf][(16 + skey) * ALDK + 4 * sq4]) = pk1;
+    };
+    auto stash_v = [&](int buf) {
+        *reinterpret_cast<float4 *>(&Vs[buf][skey * FHD + 4 * sq4]) = pv0;
+        *reinterpret_cast<float4 *>(&Vs[buf][(16 + skey) * FHD + 4 * sq4]) = pv1;
+    };
+    f32x16 o[2], sc;          // sc: the scores of the tile whose softmax is due
 #pragma unroll
-    for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = 0.0f;
+    for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = sc[e] = 0.0f;
     float m = -1.0e30f, l = 0.0f;
     const int n_kt = (T + AKT - 1) / AKT;
-    fetch(0);
-    stash(0);
+    // prologue: K(0), V(0), K(1) in LDS; S^T of tile 0
+    fetch_k(0);
+    fetch_v(0);
+    stash_k(0);
+    stash_v(0);
+    fetch_k(min(1, n_kt - 1) * AKT);
+    stash_k(1);
     __syncthreads();
-    for (int kt = 0; kt < n_kt; kt++) {
-        const int buf = kt & 1;
-        fetch(min(kt + 1, n_kt - 1) * AKT);         // unconditional and pinned here: see gemm_f32_kernel
+    if (wave_on) {
+        const float *A = &Ks[0][r * ALDK + 4 * h];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
+#pragma unroll
+            for (int st = 0; st < 4; st++) sc = mfma32(a[st], qreg[4 * g + st], sc);
+        }
+    }
+    __syncthreads();          // iteration 0 overwrites Ks[0]
+    float vf0[16], vf1[16];
+#define ATT_SLICE_MAX()                                                                                               \
+    {                                                                                                                 \
+        mx = m;                                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; e++) mx = fmaxf(mx, sc[e]);                                         \
+    }
+#define ATT_SLICE_ALPHA()                                                                                             \
+    {                                                                                                                 \
+        const u32x2 w_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
+        mx = fmaxf(__uint_as_float(w_[0]), __uint_as_float(w_[1]));      /* xor-32 exchange without the LDS round trip */ \
+        alpha = __builtin_amdgcn_exp2f(m - mx);                                                                       \
+        m = mx;                                                                                                       \
+    }
+#define ATT_SLICE_EXP(e0_)                                                                                            \
+    _Pragma("unroll") for (int e = (e0_); e < (e0_) + 4; e++) {                                                       \
+        sc[e] = __builtin_amdgcn_exp2f(sc[e] - mx);                                                                   \
+        ps += sc[e];                                                                                                  \
+    }
+#define ATT_VREADS(dst_, off_, e0_)                                                                                   \
+    _Pragma("unroll") for (int e = (e0_); e < (e0_) + 8; e++) dst_[e] = V[crow(e, h) * FHD + (off_) + r];
+    for (int kt = 0; kt + 1 < n_kt; kt++) {
+        const int kb = (kt + 1) & 1, vb = kt & 1;
+        fetch_k(min(kt + 2, n_kt - 1) * AKT);          // unconditional and pinned here: see gemm_f32_kernel
+        fetch_v((kt + 1) * AKT);
         __builtin_amdgcn_sched_barrier(0);
         if (wave_on) {
-            f32x16 s;
+            const float *A = &Ks[kb][r * ALDK + 4 * h], *V = &Vs[vb][0];
+            f32x4 a[8];
 #pragma unroll
-            for (int e = 0; e < 16; e++) s[e] = 0.0f;
-            const float *A = &Ks[buf][r * ALDK + 4 * h];
-#pragma unroll
-            for (int g = 0; g < 8; g++) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
-#pragma unroll
-                for (int st = 0; st < 4; st++) s = mfma32(a[st], qreg[4 * g + st], s);
-            }
-            // the A operands of the second product (V^T fragments) do not depend on the softmax: the first half (d < 32) is
-            // requested now and used after it, the second half (d >= 32) goes out in front of the first half's 16 MFMAs
-            float vf0[16], vf1[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) vf0[e] = Vs[buf][crow(e, h) * FHD + r];
-            __builtin_amdgcn_sched_barrier(0);       // keeps the LDS reads HERE (the scheduler sinks each one to its MFMA otherwise)
-            if (kt == n_kt - 1) {                    // only the last tile can hold keys beyond T
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (kt * AKT + crow(e, h) >= T) s[e] = -INFINITY;
-                asm volatile("" ::: "memory");       // keeps this a branch (if-converted it is 17 selects in every tile)
-            }
-            float mx = m;
-#pragma unroll
-            for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[e]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float alpha = __builtin_amdgcn_exp2f(m - mx);
-            m = mx;
-            float ps = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                s[e] = __builtin_amdgcn_exp2f(s[e] - mx);
-                ps += s[e];
-            }
-            l = l * alpha + ps;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                o[0][e] *= alpha;
-                o[1][e] *= alpha;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; e++) vf1[e] = Vs[buf][crow(e, h) * FHD + 32 + r];
+            for (int g = 0; g < 8; g++) a[g] = *reinterpret_cast<const f32x4 *>(A + 8 * g);
             __builtin_amdgcn_sched_barrier(0);
-            // O^T += V^T P^T: step e multiplies keys (crow(e, 0), crow(e, 1)); A operand = V[key(h)][32 dt + r]
+            f32x16 sn;
 #pragma unroll
-            for (int e = 0; e < 16; e++) o[0] = mfma32(vf0[e], s[e], o[0]);
+            for (int e = 0; e < 16; e++) sn[e] = 0.0f;
+            float mx, alpha, ps = 0.0f;
+#define ATT_MMA_S(g_)                                                                                                 \
+    _Pragma("unroll") for (int st = 0; st < 4; st++) sn = mfma32(a[g_][st], qreg[4 * (g_) + st], sn);                 \
+    __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(0)
+            ATT_SLICE_MAX()
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(1)
+            ATT_SLICE_ALPHA()
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(2)
+            ATT_SLICE_EXP(0)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(3)
+            ATT_SLICE_EXP(4)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(4)
+            ATT_SLICE_EXP(8)
+            ATT_VREADS(vf0, 0, 0)          // the V^T fragments take the registers the K fragments leave
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(5)
+            ATT_SLICE_EXP(12)
+            l = l * alpha + ps;
+            ATT_VREADS(vf1, 32, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(6)
 #pragma unroll
-            for (int e = 0; e < 16; e++) o[1] = mfma32(vf1[e], s[e], o[1]);
+            for (int e = 0; e < 16; e++) o[0][e] *= alpha;
+            ATT_VREADS(vf0, 0, 8)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MMA_S(7)
+#pragma unroll
+            for (int e = 0; e < 16; e++) o[1][e] *= alpha;
+            ATT_VREADS(vf1, 32, 8)
+            __builtin_amdgcn_sched_barrier(0);
+            // O^T += V^T P^T: step e multiplies keys (crow(e, 0), crow(e, 1)); A operand = V[key(h)][32 dt + r]; two independent chains
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                o[0] = mfma32(vf0[e], sc[e], o[0]);
+                o[1] = mfma32(vf1[e], sc[e], o[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stash_k(vb);          // K(kt + 2) over K(kt), last read in iteration kt - 1; V(kt + 1) over V(kt - 1) likewise
+            stash_v(kb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 8; e < 16; e++) {
+                o[0] = mfma32(vf0[e], sc[e], o[0]);
+                o[1] = mfma32(vf1[e], sc[e], o[1]);
+            }
+            sc = sn;
+        } else {
+            stash_k(vb);
+            stash_v(kb);
         }
-        stash(buf ^ 1);          // the other buffer: last read in iteration kt - 1, behind the barrier below (unconditional: see the GEMM)
         __syncthreads();
     }
-    if (!wave_on || qt * 32 + r >= T) return;
+    if (!wave_on) return;
+    {   // last tile: the only one that can hold keys beyond T
+        const int kt = n_kt - 1;
+        const float *V = &Vs[kt & 1][0];
+        ATT_VREADS(vf0, 0, 0)
+        ATT_VREADS(vf0, 0, 8)
+        ATT_VREADS(vf1, 32, 0)
+        ATT_VREADS(vf1, 32, 8)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if (kt * AKT + crow(e, h) >= T) sc[e] = -INFINITY;
+        float mx, alpha, ps = 0.0f;
+        ATT_SLICE_MAX()
+        ATT_SLICE_ALPHA()
+        ATT_SLICE_EXP(0)
+        ATT_SLICE_EXP(4)
+        ATT_SLICE_EXP(8)
+        ATT_SLICE_EXP(12)
+        l = l * alpha + ps;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            o[0][e] *= alpha;
+            o[1][e] *= alpha;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            o[0] = mfma32(vf0[e], sc[e], o[0]);
+            o[1] = mfma32(vf1[e], sc[e], o[1]);
+        }
+    }
+#undef ATT_SLICE_MAX
+#undef ATT_SLICE_ALPHA
+#undef ATT_SLICE_EXP
+#undef ATT_VREADS
+#undef ATT_MMA_S
+    if (qt * 32 + r >= T) return;
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const int frame = bh / FH, head = bh % FH;
