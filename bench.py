@@ -216,6 +216,11 @@ def main():
         sys.exit(2)
     if action == "spawn":
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever a library writes to file descriptor 1 from here on (gloo's
+    # connection notes, a runtime's warnings) is sent to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -726,7 +731,8 @@ def main():
         if not ok and rehearse is None:
             # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
             res["value_unverified"], res["value"] = res["value"], None
-        print(json.dumps(res))
+        json_out.write(json.dumps(res) + "\n")
+        json_out.flush()
         if not ok:
             sys.exit(1)
     if world > 1:

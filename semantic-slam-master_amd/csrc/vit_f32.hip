@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform BY CONSTRUCTION: the B loads' scalar offsets depend on it
     const int wm = wave >> 1, wn = wave & 1;
 #ifdef SSLAM_CLOCK_PROBE
-    const unsigned long long pr_t0 = clock64();
+    const unsigned long long pr_t0 = clock64(), pr_w0 = wall_clock64();
 #endif
     // XCD-aware order: workgroup b runs on XCD b % 8, and the ntn workgroups that share an A tile (one row tile, all column tiles)
     // share an L2: row tile = x + 8 (j / ntn), column tile = j % ntn for b = 8 j + x
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
         o_[0] = pr_t1 - pr_t0;
         o_[1] = pr_t2 - pr_t1;
         o_[2] = clock64() - pr_t2;
-        o_[3] = pr_t0;
+        o_[3] = wall_clock64() - pr_w0;      // 100 MHz ticks over the workgroup's life: cycles / ticks = the shader clock
     }
 #endif
 }
@@ -467,6 +467,10 @@ __global__ __launch_bounds__(64) void prefix_rows_f32_kernel(const float *__rest
 // and 83 frames.  sched_barrier pins the interleave (left alone, hipcc issues the MFMAs back to back).
 // K runs one tile ahead of V in LDS: iteration kt reads K(kt + 1) and V(kt), stores K(kt + 2) and V(kt + 1).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#ifdef SSLAM_CLOCK_PROBE
+// probe builds only (tools/vit_f32_probe.py): wave 0 of the first 8192 workgroups stamps shader cycles and the 100 MHz real-time counter
+__device__ unsigned long long g_probe_attn_f32[4 * 8192];
+#endif
 constexpr int AW = 4, AKT = 32, ALDK = 68;      // waves per workgroup (4 x 32 queries; one wave per SIMD and workgroup), keys per tile
 __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                             float *__restrict__ y, int T, int nbh, int subs) {
@@ -476,6 +480,9 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
     const int b = blockIdx.x, chunk = b / (8 * subs), within = b % (8 * subs);
     const int bh = chunk * 8 + within % 8, sub = within / 8;
     if (bh >= nbh) return;
+#ifdef SSLAM_CLOCK_PROBE
+    const unsigned long long pr_c0 = clock64(), pr_w0 = wall_clock64();
+#endif
     const int qt = sub * AW + wave;
     const int n_qt = (T + 31) / 32;
     const bool wave_on = qt < n_qt;                               // a wave without queries still helps staging
@@ -625,6 +632,15 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
         }
         __syncthreads();
     }
+#ifdef SSLAM_CLOCK_PROBE
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long *o_ = g_probe_attn_f32 + 4 * blockIdx.x;
+        o_[0] = clock64() - pr_c0;
+        o_[1] = wall_clock64() - pr_w0;
+        o_[2] = pr_c0;
+        o_[3] = pr_w0;
+    }
+#endif
     if (!wave_on) return;
     {   // last tile: the only one that can hold keys beyond T
         const int kt = n_kt - 1;
@@ -678,6 +694,13 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
             *reinterpret_cast<float4 *>(dst + 32 * dt + 8 * g) = t;
         }
 }
+#ifdef SSLAM_CLOCK_PROBE
+}  // namespace
+extern "C" int sslam_probe_attn_f32(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe_attn_f32), sizeof(unsigned long long) * 4 * 8192) == hipSuccess ? 0 : -3;
+}
+namespace {
+#endif
 
 inline size_t ws_align(long long b) { return ((size_t)b + 255) & ~(size_t)255; }
 
