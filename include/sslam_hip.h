@@ -267,7 +267,8 @@ int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, 
  * per-layer matrices - wqkv = rows [q_proj; k_proj; v_proj] (1152, 384), wo (384, 384), wup (1536, 384), wdown (384, 1536) - are
  * re-ordered by sslam_vit_f32_pack_linear_host into the MFMA fragment order their kernel streams from L2 (same values, same
  * size); bqkv has zeros for the k rows; patch_w is the Conv2d weight viewed as (384, 768), as it is; prefix, rope_cos / rope_sin
- * as in sslam_vit_weights_t.
+ * as in sslam_vit_weights_t - DINOv3's construction, the 32 angles of a cell tiled twice: columns d and d + 32 of a row are equal
+ * and this entry reads columns 0..31 only (a caller with other tables must not use it; sslam_amd/vit_hip.py checks).
  * Workspace: sslam_vit_f32_workspace_bytes(n_frames, size) bytes (x, LayerNorm output, q / k / v, MLP hidden: 13.7 KB per token). */
 typedef struct {
     const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ls1, *ln2_g, *ln2_b, *wup, *bup, *wdown, *bdown, *ls2;

@@ -89,13 +89,14 @@ struct TQKV {                 // + bias, RoPE on the patch tokens of q and k, sc
             for (int qd = 0; qd < 4; qd++) {
                 // d = 8 qd + 4 h + i in the first half of the head (tile ni = 0), d + 32 in the second (ni = 1): rotate_half pairs them
                 const float4 b0 = *reinterpret_cast<const float4 *>(b + n0 + 8 * qd + 4 * h), b1 = *reinterpret_cast<const float4 *>(b + n0 + 32 + 8 * qd + 4 * h);
-                float4 c0 = make_float4(1.f, 1.f, 1.f, 1.f), c1 = c0, s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+                // DINOv3's tables are [angles, angles] (the 32 angles tiled twice): columns d and d + 32 are equal, only 0..31 are read
+                // (every 16-byte access of this epilogue touches 32 different lines - its cost is the NUMBER of such accesses)
+                float4 c0 = make_float4(1.f, 1.f, 1.f, 1.f), s0 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rot) {
                     c0 = *reinterpret_cast<const float4 *>(ct + 8 * qd);
-                    c1 = *reinterpret_cast<const float4 *>(ct + 32 + 8 * qd);
                     s0 = *reinterpret_cast<const float4 *>(st + 8 * qd);
-                    s1 = *reinterpret_cast<const float4 *>(st + 32 + 8 * qd);
                 }
+                const float4 c1 = c0, s1 = s0;
                 const float v0x = acc[0][ri][4 * qd] + b0.x, v0y = acc[0][ri][4 * qd + 1] + b0.y, v0z = acc[0][ri][4 * qd + 2] + b0.z, v0w = acc[0][ri][4 * qd + 3] + b0.w;
                 const float v1x = acc[1][ri][4 * qd] + b1.x, v1y = acc[1][ri][4 * qd + 1] + b1.y, v1z = acc[1][ri][4 * qd + 2] + b1.z, v1w = acc[1][ri][4 * qd + 3] + b1.w;
                 // out[d] = x[d] cos[d] - x[d + 32] sin[d] (d < 32), x[d] cos[d] + x[d - 32] sin[d] (d >= 32)

@@ -181,7 +181,11 @@ class HipViTF32:
         g = s // 16
         if g not in self._rope:
             cos, sin = self.vit.rope_tables(g, g, self.device)
-            self._rope[g] = (cos.float().contiguous(), sin.float().contiguous())
+            cos, sin = cos.float().contiguous(), sin.float().contiguous()
+            if not (torch.equal(cos[:, :32], cos[:, 32:]) and torch.equal(sin[:, :32], sin[:, 32:])):
+                raise ValueError("sslam_vit_forward_f32 reads columns 0..31 of the RoPE tables (DINOv3 tiles its 32 angles twice); "
+                                 "these tables differ between d and d + 32")
+            self._rope[g] = (cos, sin)
         self.w.rope_cos, self.w.rope_sin = self._rope[g][0].data_ptr(), self._rope[g][1].data_ptr()
         step = chunk or self.chunk_frames(s)
         need = lib.vit_f32_workspace_bytes(min(n, step), s)
