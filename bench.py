@@ -416,6 +416,38 @@ def main():
                       "equal_to_resident_pass": bool(torch.equal(ouv[cfg.spacing]["matches"], ov["matches"]) and
                                                      torch.equal(ouv["frames"]["descriptors"], ov["descriptors"]))}
             del ouv, pin_v
+        def agreement(oa, ob):
+            """keypoint sets per frame and matches as (cell, cell) pairs of pass ob against pass oa (same frames)"""
+            ia, ib = oa["idx"].cpu().numpy(), ob["idx"].cpu().numpy()
+            same = float(np.mean([np.intersect1d(a_, b_).size / float(np.unique(a_).size) for a_, b_ in zip(ia, ib)]))
+            ma, mb = oa["matches"].cpu().numpy(), ob["matches"].cpu().numpy()
+            ca, cb = oa["match_count"].cpu().numpy(), ob["match_count"].cpu().numpy()
+            hit_ = tot_ = 0
+            for p_ in range(n - 1):
+                sa = set(zip(ia[p_][ma[p_, :ca[p_], 0]].tolist(), ia[p_ + 1][ma[p_, :ca[p_], 1]].tolist()))
+                sb = set(zip(ib[p_][mb[p_, :cb[p_], 0]].tolist(), ib[p_ + 1][mb[p_, :cb[p_], 1]].tolist()))
+                hit_ += len(sa & sb)
+                tot_ += len(sa)
+            return same, hit_, tot_
+
+        # the whole path in its throughput forms: bf16 HIP ViT + bf16 conv stack / descriptor MLP (BASELINE configs[1]'s mode with A1
+        # inside), fp32 matcher; agreement against the pass above (bf16 ViT, exact fp32 stages)
+        all_bf16 = None
+        if not args.no_bf16:
+            import dataclasses as _dc
+            pipe_vb = SequencePipeline(_dc.replace(cfg, precision="bf16"), ssd, rsd, device=dev, vit=pipe_v.vit_hip.vit)
+            pipe_vb.run(imgs)
+            torch.cuda.synchronize()
+            tvb = time.perf_counter()
+            for _ in range(nv):
+                ovb = pipe_vb.run(imgs)
+            torch.cuda.synchronize()
+            dtvb = (time.perf_counter() - tvb) / nv
+            kpb, hitb, totb = agreement(ov, ovb)
+            all_bf16 = {"value": round(n / dtvb, 2), "unit": "frames/s", "ms_per_step": round(dtvb * 1e3, 3),
+                        "what": "images -> A0 -> bf16 HIP ViT -> A2 -> bf16 A3 -> A4/A5 -> bf16 A6+A7 -> A9 -> fp32 M1",
+                        "keypoint_set_agreement_vs_exact_stages": round(kpb, 4), "match_agreement_vs_exact_stages": round(hitb / max(totb, 1), 4)}
+            del ovb, pipe_vb
         # reference numerics for A1 (the reference's timm ViT is fp32, dino_backbone.py:85): the same pass with the tokens from
         # the eager fp32 torch definition of the same weights (what DinoBackbone(vit_precision="fp32") runs), its rate, and the
         # agreement of the bf16 HIP-ViT pass with it on THIS workload: keypoint sets per frame, matches as (cell, cell) pairs
@@ -455,16 +487,7 @@ def main():
             rel_hip_eager = float((tok32[:ne] - toke).norm() / toke.norm())
             tok16 = pipe_v.tokens_from_images(imgs)
             tok_rel = float((tok16 - tok32).norm() / tok32.norm())
-            i32, i16 = o32["idx"].cpu().numpy(), ov["idx"].cpu().numpy()
-            kp_same = float(np.mean([np.intersect1d(a_, b_).size / float(np.unique(a_).size) for a_, b_ in zip(i32, i16)]))
-            m32, m16 = o32["matches"].cpu().numpy(), ov["matches"].cpu().numpy()
-            c32, c16 = o32["match_count"].cpu().numpy(), ov["match_count"].cpu().numpy()
-            hit = tot = 0
-            for p_ in range(n - 1):
-                s32 = set(zip(i32[p_][m32[p_, :c32[p_], 0]].tolist(), i32[p_ + 1][m32[p_, :c32[p_], 1]].tolist()))
-                s16 = set(zip(i16[p_][m16[p_, :c16[p_], 0]].tolist(), i16[p_ + 1][m16[p_, :c16[p_], 1]].tolist()))
-                hit += len(s32 & s16)
-                tot += len(s32)
+            kp_same, hit, tot = agreement(o32, ov)
             tf32 = n * vit_flop / (vit32_ms * 1e-3) / 1e12
             fp32_leg = {"value": round(n / dt32, 2), "unit": "frames/s", "ms_per_step": round(dt32 * 1e3, 3),
                         "what": "images -> A0 -> HIP ViT-S/16 with fp32 operands on the fp32 matrix pipe (sslam_vit_forward_f32: the "
@@ -487,7 +510,7 @@ def main():
                                 "launch_ms": round(vit_ms, 3), "flop_per_launch": int(n * vit_flop),
                                 "note": "dense bf16 MFMA peak (spec); a pure bf16 MFMA loop on random data sustains ~1.3-1.5 PFLOP/s on this chip (DVFS)"},
                    "what": "images -> A0 -> HIP ViT-S/16 (A1, bf16 MFMA, random DINOv3-architecture weights) -> A2..A9 -> M1",
-                   "with_upload": vit_up, "fp32_reference_numerics": fp32_leg,
+                   "with_upload": vit_up, "fp32_reference_numerics": fp32_leg, "all_bf16": all_bf16,
                    "vit_gflop_per_frame": round(vit_flop / 1e9, 2), "matches_per_pair": round(float(ov["match_count"].float().mean().item()), 1)}
         del ov
 
