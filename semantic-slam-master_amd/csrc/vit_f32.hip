@@ -279,13 +279,17 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
 //   * ring of four groups (16 registers each): three groups = 3 072 matrix cycles of latency cover for the A rows (MALL / HBM).
 // Per group and wave: 16 MFMAs beside 4 loads and nothing else.
 // Three forms of this kernel were built and clock-probed (tools/vit_f32_probe.py): LDS-staged with two barriers per k tile (the
-// generic kernel above), LDS-staged A + streamed B with a third of its instructions, and this one.  All three run at the same
-// rate (QKV 0.65, up 0.72, down 0.78 of the nominal peak): a workgroup lives ~190 k cycles for 147 k of matrix time in the K = 384
-// GEMMs, whatever the loop looks like - the k loop itself is within 6 % of the matrix time (13.0 k cycles per k tile against
-// 12.3 k), what is left is (i) the epilogue of a 12-step GEMM: ~1 000 vector instructions that issue at about one per
-// co-resident MFMA (50-70 k cycles), only partly covered by the two other workgroups of the CU, and (ii) the clock the chip
-// holds in these kernels, 2.1 GHz (138 TFLOP/s) against 2.27 in a bare MFMA loop.  Raising the issue priority of the epilogue
-// (s_setprio 3) changes neither its length nor the kernel's.  This form is kept because it is the simplest.
+// generic kernel above), LDS-staged A + streamed B with a third of its instructions, and this one.  All three ran at the same
+// rate.  Where the time goes (probe: shader cycles against the 100 MHz real-time counter - the chip holds 2.31-2.36 GHz in these
+// kernels, so the nominal 2.4 GHz peak is 3 % away, not more): the k loop is within 6 % of its matrix time (13.0 k cycles per k
+// tile against 12.3 k); with the stores of the QKV epilogue switched off the kernel takes 425 us for 380 us of matrix time, with
+// them 511 (482 after the RoPE tables were halved) - and it makes no difference whether those stores go to HBM or to a 4 MB
+// region that stays in L2, whether the first round of workgroups starts staggered over a workgroup's life, or what issue priority
+// the epilogue has.  Its cost is the NUMBER of vector-memory instructions whose 64 lanes touch 32 different 128-byte lines (a lane
+// owns a row): ~50 cycles of the CU's address path each, 56 per wave in the first form.  A persistent form (768 workgroups
+// looping over the tiles) was slower (QKV 528, up 670): the hardware's dispatch desynchronises the workgroups, a static loop
+// keeps all epilogues of a CU in step.  The slot turnover (end of one workgroup to the start of the next) is ~7 us, 10 % of a
+// K = 384 workgroup's life.
 #ifdef SSLAM_CLOCK_PROBE
 // probe builds only (tools/vit_f32_probe.py): wave 0 of the first 8192 workgroups stamps start / loop entry / loop exit / end
 __device__ unsigned long long g_probe_gemm_f32[4 * 8192];
