@@ -441,3 +441,63 @@ def test_rccl_group_of_one_rank(T):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "rccl-one-rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_online_stepper_tokens_in_equals_the_batched_run(T, pipe, use_graph):
+    """The online caller's loop (test/test_tracking.py:146-178: one frame at a time, the previous frame's descriptors kept):
+    FrameStepper's per-frame outputs and its matches against the previous frame are bit-identical to the same frames going
+    through SequencePipeline.run as one batch - as ordinary launches and replayed from a captured HIP graph (0 library calls
+    per frame after the capture)."""
+    from sslam_amd import lib
+    from sslam_amd.online import FrameStepper
+    n = 6
+    imgs = T.from_numpy(synth.image_sequence(n)).cuda()
+    toks = T.from_numpy(synth.token_sequence(n, 28)).cuda()
+    want = pipe.run(imgs, tokens=toks)
+    st = FrameStepper(pipe, 480, 640, use_graph=use_graph, tokens_in=True)
+    with pytest.raises(ValueError, match="tokens"):
+        st.step(imgs[0])
+    st.reset()
+    for rnd in range(2):                       # a second pass after reset(): the first frame has no previous one again
+        for i in range(n):
+            n0 = lib.launch_count()
+            o = st.step(imgs[i].cpu() if i == 2 else imgs[i], toks[i])        # a host-resident frame is accepted too
+            calls = lib.launch_count() - n0
+            if use_graph and (rnd or i):
+                assert calls == 0, "a replayed step issues no library call"
+            for k in ("idx", "descriptors", "intensity", "scores", "saliency", "keypoints_pixel"):
+                assert T.equal(o[k], want[k][i]), (k, i)
+            if i == 0:
+                assert o["matches"] is None and o["match_count"] is None
+            else:
+                c = int(o["match_count"])
+                assert c == int(want["match_count"][i - 1]) and c > 0
+                assert T.equal(o["matches"][:c], want["matches"][i - 1][:c]) and T.equal(o["quality"][:c], want["quality"][i - 1][:c])
+        st.reset()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_online_stepper_with_the_hip_vit(T, prec):
+    """The same loop with A0 + A1 inside the step (images in): graph replay == ordinary launches == the batched run, bit for bit,
+    for both ViT forms (a frame's tokens do not depend on what else is in the launch group)."""
+    from sslam_amd.online import FrameStepper
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    from sslam_amd.vit import DinoV3ViT
+    T.manual_seed(3)
+    n = 4
+    imgs = T.from_numpy(synth.image_sequence(n)).cuda()
+    pv = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda",
+                          vit=DinoV3ViT().cuda().eval(), vit_precision=prec)
+    want = pv.run(imgs)
+    for use_graph in (False, True):
+        st = FrameStepper(pv, 480, 640, use_graph=use_graph)
+        for i in range(n):
+            o = st.step(imgs[i])
+            for k in ("idx", "descriptors", "intensity", "scores"):
+                assert T.equal(o[k], want[k][i]), (use_graph, k, i)
+            if i:
+                c = int(o["match_count"])
+                assert c == int(want["match_count"][i - 1]) and T.equal(o["matches"][:c], want["matches"][i - 1][:c])
+    with pytest.raises(Exception, match="without a ViT"):
+        FrameStepper(SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda"), 480, 640)

@@ -67,6 +67,27 @@ def measure(pipe, toks, imgs, vit_pipe=None, reps=100):
     for _ in range(reps):
         step()
     out["step_wall_ms_tokens_in"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    # the online loop on static buffers (sslam_amd/online.py): ordinary launches against replay of the captured HIP graph
+    from sslam_amd.online import FrameStepper
+    online = {}
+    for name, p_, tok_in in (("tokens_in", pipe, True),) + ((("vit_inside", vit_pipe, False),) if vit_pipe is not None else ()):
+        for graph in (False, True):
+            st = FrameStepper(p_, imgs.shape[1], imgs.shape[2], use_graph=graph, tokens_in=tok_in)
+
+            def frame(i=[0]):
+                i[0] ^= 1
+                o = st.step(imgs[i[0]], toks[i[0]] if tok_in else None)
+                return o
+
+            for _ in range(10):
+                frame()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                frame()
+            torch.cuda.synchronize()
+            online[f"{name}_{'graph' if graph else 'launches'}_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    out["online_step_ms"] = online
     return out
 
 
