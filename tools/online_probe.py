@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np, torch, synth
