@@ -72,12 +72,13 @@ struct TQKV {                 // + bias, RoPE on the patch tokens of q and k, sc
     const float *b, *cosv, *sinv;
     float *q, *k, *v;
     int T;
+    template <int RI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
         const int which = n0 / FD, head = (n0 % FD) / FHD;            // a wave's 64 columns are exactly one head of q, k or v
         float *dst = which == 0 ? q : (which == 1 ? k : v);
         const bool rope = which < 2;
 #pragma unroll
-        for (int ri = 0; ri < 2; ri++) {
+        for (int ri = 0; ri < RI; ri++) {
             const long long row = m0 + 32 * ri + r;
             if (row >= M) continue;
             const long long f = row / T;
@@ -116,10 +117,11 @@ struct EpiResidual {          // x += ls * (acc + bias)
     static constexpr bool TRANSPOSED = false;
     const float *b, *ls;
     float *x;
+    template <int RI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
         const float bv0 = b[n0 + r], bv1 = b[n0 + 32 + r], lv0 = ls[n0 + r], lv1 = ls[n0 + 32 + r];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {            // 16 rows at a time: bounded temporaries
+        for (int mt = 0; mt < RI; mt++) {            // 16 rows at a time: bounded temporaries
             float xv[2][16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -158,9 +160,10 @@ struct TGelu {                // hidden = gelu(acc + bias), the erf form (torch 
     static constexpr bool TRANSPOSED = true;
     const float *b;
     float *hid;
+    template <int RI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
 #pragma unroll
-        for (int ri = 0; ri < 2; ri++) {
+        for (int ri = 0; ri < RI; ri++) {
             const long long row = m0 + 32 * ri + r;
             if (row >= M) continue;
             float *hr = hid + row * FMLP + n0 + 4 * h;
@@ -295,9 +298,13 @@ int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hi
 __device__ unsigned long long g_probe_gemm_f32[4 * 8192];
 __device__ int g_probe_gemm_sel[2];        // (K, column tiles) of the GEMM to stamp
 #endif
-template <class Epi>
+// RI = row tiles of 32 per wave: 2 (workgroup = 128 x 128, the throughput form) or 1 (64 x 128: twice the workgroups, half the
+// work each - the form for a few frames, where a launch of the big form leaves most CUs empty and its time is one workgroup's
+// latency; same k order per output, so a frame's tokens do not depend on the form).
+template <class Epi, int RI>
 __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
                                                                 long long M, int ntn, Epi epi) {
+    constexpr int BM_ = 64 * RI;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform BY CONSTRUCTION: the B loads' scalar offsets depend on it
     const int wm = wave >> 1, wn = wave & 1;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     // XCD-aware order: workgroup b runs on XCD b % 8, and the ntn workgroups that share an A tile (one row tile, all column tiles)
     // share an L2: row tile = x + 8 (j / ntn), column tile = j % ntn for b = 8 j + x
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
-    const long long m0 = (long long)(bx + 8 * (bj / ntn)) * GBM;
+    const long long m0 = (long long)(bx + 8 * (bj / ntn)) * BM_;
     if (m0 >= M) return;
     const int n0 = (bj % ntn) * GBN;
     const int groups = K / 8;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     // increasing k; nothing here needs that).
     // A fragments: rows clamped to M - 1 (the epilogue masks them); byte offset of lane (r, h) in group g: row * lda * 4 + 32 g + 16 h
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0xfffffffe, 0x00020000);
-    long long ra = m0 + wm * 64 + r, rb2 = ra + 32;
+    long long ra = m0 + wm * (32 * RI) + r, rb2 = ra + 32;
     if (ra > M - 1) ra = M - 1;
     if (rb2 > M - 1) rb2 = M - 1;
     const unsigned ao0 = (unsigned)(ra * lda * 4 + 16 * h), ao1 = (unsigned)(rb2 * lda * 4 + 16 * h);
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     Frag q0, q1, q2, q3;
     auto load = [&](Frag &d, int G) {
         d.a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao0, G * 32, 0));
-        d.a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao1, G * 32, 0));
+        if (RI == 2) d.a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao1, G * 32, 0));
         d.b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
         d.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
     };
@@ -352,14 +359,14 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
         for (int st = 0; st < 4; st++) {
             if (Epi::TRANSPOSED) {
                 acc[0][0] = mfma32(c.b0[st], c.a0[st], acc[0][0]);
-                acc[0][1] = mfma32(c.b0[st], c.a1[st], acc[0][1]);
+                if (RI == 2) acc[0][1] = mfma32(c.b0[st], c.a1[st], acc[0][1]);
                 acc[1][0] = mfma32(c.b1[st], c.a0[st], acc[1][0]);
-                acc[1][1] = mfma32(c.b1[st], c.a1[st], acc[1][1]);
+                if (RI == 2) acc[1][1] = mfma32(c.b1[st], c.a1[st], acc[1][1]);
             } else {
                 acc[0][0] = mfma32(c.a0[st], c.b0[st], acc[0][0]);
                 acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
-                acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
-                acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
+                if (RI == 2) acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
+                if (RI == 2) acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
             }
         }
     };
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
 #ifdef SSLAM_CLOCK_PROBE
     const unsigned long long pr_t2 = clock64();
 #endif
-    epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
+    epi.template operator()<RI>(acc, m0 + wm * (32 * RI), n0 + wn * 64, r, h, M);
 #ifdef SSLAM_CLOCK_PROBE
     if (tid == 0 && blockIdx.x < 8192 && K == g_probe_gemm_sel[0] && ntn == g_probe_gemm_sel[1]) {
         unsigned long long *o_ = g_probe_gemm_f32 + 4 * blockIdx.x;
@@ -409,11 +416,19 @@ extern "C" int sslam_probe_gemm_f32(unsigned long long *host) {
 }
 #endif
 
+#ifndef GEMM_SMALL_BELOW
+#define GEMM_SMALL_BELOW 768
+#endif
 template <class Epi>
 int launch_gemm_rows(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
     const int ntn = N / GBN;
     const long long blocks = ((M + GBM - 1) / GBM + 7) / 8 * 8 * ntn;        // row tiles padded to a multiple of 8 (XCD-aware order)
-    hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
+    if (blocks < GEMM_SMALL_BELOW) {             // fewer workgroups than the chip has slots (256 CUs x 3): the 64-row form
+        const long long blocks64 = ((M + 63) / 64 + 7) / 8 * 8 * ntn;
+        hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi, 1>), dim3((unsigned)blocks64), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
+    }
     sslam_count_launches(1);
     return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
 }

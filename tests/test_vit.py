@@ -187,6 +187,26 @@ def test_hip_vit_f32_matches_fp32_definition(size, frames):
 
 
 @pytest.mark.gpu
+def test_hip_vit_f32_small_and_big_launch_forms_agree_bit_for_bit():
+    """The per-layer GEMM has a 64-row form for launches that would leave most CUs empty (a few frames: what the reference's
+    per-frame callers send) and the 128-row throughput form; both sum every output over k in the same order, so a frame's
+    tokens do not depend on how many frames share its launch: frames 0..1 alone (all four GEMMs in the small form), inside 20
+    frames (QKV and up + GELU big, the two residual GEMMs small) and inside 48 frames (all big) - identical bits."""
+    from sslam_amd.vit_hip import HipViTF32
+    _, mine = _hf_pair(2)
+    mine = mine.cuda()
+    torch.manual_seed(5)
+    x = torch.randn(48, 3, 448, 448, device="cuda")
+    hv = HipViTF32(mine)
+    with torch.no_grad():
+        t48 = hv.forward_features(x)
+        t20 = hv.forward_features(x[:20])
+        t2 = hv.forward_features(x[:2])
+        t1 = hv.forward_features(x[1:2])
+    assert torch.equal(t2, t48[:2]) and torch.equal(t20, t48[:20]) and torch.equal(t1[0], t48[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("frames", [2, 12])       # the few-frame launch shapes and the throughput ones (fused MLP)
 def test_hip_vit_layernorm_with_dc_offset_and_outlier_channels(frames):
     """The LayerNorm folded into the GEMM prologues takes ONE-pass statistics (sum, sum of squares from the producing

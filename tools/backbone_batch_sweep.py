@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
+from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a variant build of the library (experiments)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 from models.dino_backbone import DinoBackbone
 from sslam_amd.vit import DinoV3ViT
 torch.manual_seed(0)
