@@ -72,8 +72,9 @@ struct TQKV {                 // + bias, RoPE on the patch tokens of q and k, sc
     const float *b, *cosv, *sinv;
     float *q, *k, *v;
     int T;
-    template <int RI>
+    template <int RI, int NI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        static_assert(NI == 2, "RoPE pairs (d, d + 32) live in the wave's two column tiles");
         const int which = n0 / FD, head = (n0 % FD) / FHD;            // a wave's 64 columns are exactly one head of q, k or v
         float *dst = which == 0 ? q : (which == 1 ? k : v);
         const bool rope = which < 2;
@@ -117,25 +118,27 @@ struct EpiResidual {          // x += ls * (acc + bias)
     static constexpr bool TRANSPOSED = false;
     const float *b, *ls;
     float *x;
-    template <int RI>
+    template <int RI, int NI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
-        const float bv0 = b[n0 + r], bv1 = b[n0 + 32 + r], lv0 = ls[n0 + r], lv1 = ls[n0 + 32 + r];
+        float bv[NI], lv[NI];
+#pragma unroll
+        for (int nt = 0; nt < NI; nt++) bv[nt] = b[n0 + 32 * nt + r], lv[nt] = ls[n0 + 32 * nt + r];
 #pragma unroll
         for (int mt = 0; mt < RI; mt++) {            // 16 rows at a time: bounded temporaries
-            float xv[2][16];
+            float xv[NI][16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 long long row = m0 + mt * 32 + crow(e, h);
                 if (row > M - 1) row = M - 1;
-                xv[0][e] = x[row * FD + n0 + r];
-                xv[1][e] = x[row * FD + n0 + 32 + r];
+#pragma unroll
+                for (int nt = 0; nt < NI; nt++) xv[nt][e] = x[row * FD + n0 + 32 * nt + r];
             }
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const long long row = m0 + mt * 32 + crow(e, h);
                 if (row < M) {
-                    x[row * FD + n0 + r] = xv[0][e] + lv0 * (acc[mt][0][e] + bv0);
-                    x[row * FD + n0 + 32 + r] = xv[1][e] + lv1 * (acc[mt][1][e] + bv1);
+#pragma unroll
+                    for (int nt = 0; nt < NI; nt++) x[row * FD + n0 + 32 * nt + r] = xv[nt][e] + lv[nt] * (acc[mt][nt][e] + bv[nt]);
                 }
             }
         }
@@ -160,8 +163,9 @@ struct TGelu {                // hidden = gelu(acc + bias), the erf form (torch 
     static constexpr bool TRANSPOSED = true;
     const float *b;
     float *hid;
-    template <int RI>
+    template <int RI, int NI>
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[2][2], long long m0, int n0, int r, int h, long long M) const {
+        static_assert(NI == 2, "two column tiles per wave");
 #pragma unroll
         for (int ri = 0; ri < RI; ri++) {
             const long long row = m0 + 32 * ri + r;
@@ -301,13 +305,17 @@ __device__ int g_probe_gemm_sel[2];        // (K, column tiles) of the GEMM to s
 // RI = row tiles of 32 per wave: 2 (workgroup = 128 x 128, the throughput form) or 1 (64 x 128: twice the workgroups, half the
 // work each - the form for a few frames, where a launch of the big form leaves most CUs empty and its time is one workgroup's
 // latency; same k order per output, so a frame's tokens do not depend on the form).
-template <class Epi, int RI>
+// NI = column tiles of 32 per wave: 2, or 1 (with RI = 1: the four waves side by side, workgroup = 32 x 128 - the residual GEMMs of a
+// one- or two-frame launch, where even the 64-row form is 39 workgroups of which each wave runs 1 536 dependent-pair MFMAs).
+template <class Epi, int RI, int NI = 2>
 __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
                                                                 long long M, int ntn, Epi epi) {
-    constexpr int BM_ = 64 * RI;
+    static_assert(NI == 2 || (RI == 1 && !Epi::TRANSPOSED), "the one-tile wave exists for the residual epilogue only");
+    constexpr int BM_ = NI == 1 ? 32 : 64 * RI;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform BY CONSTRUCTION: the B loads' scalar offsets depend on it
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NI == 1 ? 0 : wave >> 1, wn = NI == 1 ? wave : wave & 1;
+    const int cw = wn * (32 * NI);                                    // the wave's first column inside the workgroup's 128
 #ifdef SSLAM_CLOCK_PROBE
     const unsigned long long pr_t0 = clock64(), pr_w0 = wall_clock64();
 #endif
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
     const unsigned ao0 = (unsigned)(ra * lda * 4 + 16 * h), ao1 = (unsigned)(rb2 * lda * 4 + 16 * h);
     // B fragments: packed W, fragment (column tile nt, group g) at ((nt * K / 8 + g) * 1024) bytes, lane * 16 inside it
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, 0x7fffffff, 0x00020000);
-    const int nt0 = (n0 + wn * 64) / 32;
+    const int nt0 = (n0 + cw) / 32;
     const int wo0 = nt0 * groups * 1024, wo1 = wo0 + groups * 1024, loff = lane * 16;
     struct Frag {
         f32x4 a0, a1, b0, b1;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
         d.a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao0, G * 32, 0));
         if (RI == 2) d.a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao1, G * 32, 0));
         d.b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
-        d.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
+        if (NI == 2) d.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo1 + G * 1024, 0));
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
                 if (RI == 2) acc[1][1] = mfma32(c.b1[st], c.a1[st], acc[1][1]);
             } else {
                 acc[0][0] = mfma32(c.a0[st], c.b0[st], acc[0][0]);
-                acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
+                if (NI == 2) acc[0][1] = mfma32(c.a0[st], c.b1[st], acc[0][1]);
                 if (RI == 2) acc[1][0] = mfma32(c.a1[st], c.b0[st], acc[1][0]);
                 if (RI == 2) acc[1][1] = mfma32(c.a1[st], c.b1[st], acc[1][1]);
             }
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
 #ifdef SSLAM_CLOCK_PROBE
     const unsigned long long pr_t2 = clock64();
 #endif
-    epi.template operator()<RI>(acc, m0 + wm * (32 * RI), n0 + wn * 64, r, h, M);
+    epi.template operator()<RI, NI>(acc, m0 + wm * (32 * RI), n0 + cw, r, h, M);
 #ifdef SSLAM_CLOCK_PROBE
     if (tid == 0 && blockIdx.x < 8192 && K == g_probe_gemm_sel[0] && ntn == g_probe_gemm_sel[1]) {
         unsigned long long *o_ = g_probe_gemm_f32 + 4 * blockIdx.x;
@@ -419,12 +427,23 @@ extern "C" int sslam_probe_gemm_f32(unsigned long long *host) {
 #ifndef GEMM_SMALL_BELOW
 #define GEMM_SMALL_BELOW 768
 #endif
+#ifndef GEMM_TINY_BELOW
+#define GEMM_TINY_BELOW 192
+#endif
 template <class Epi>
 int launch_gemm_rows(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
     const int ntn = N / GBN;
     const long long blocks = ((M + GBM - 1) / GBM + 7) / 8 * 8 * ntn;        // row tiles padded to a multiple of 8 (XCD-aware order)
     if (blocks < GEMM_SMALL_BELOW) {             // fewer workgroups than the chip has slots (256 CUs x 3): the 64-row form
         const long long blocks64 = ((M + 63) / 64 + 7) / 8 * 8 * ntn;
+        if constexpr (!Epi::TRANSPOSED) {
+            if (blocks64 < GEMM_TINY_BELOW) {    // still a fraction of the CUs: 32-row workgroups of four one-tile waves
+                const long long blocks32 = ((M + 31) / 32 + 7) / 8 * 8 * ntn;
+                hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi, 1, 1>), dim3((unsigned)blocks32), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
+                sslam_count_launches(1);
+                return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
+            }
+        }
         hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi, 1>), dim3((unsigned)blocks64), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);
     } else {
         hipLaunchKernelGGL((gemm_f32_rows_kernel<Epi, 2>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn, epi);

@@ -190,7 +190,8 @@ def test_hip_vit_f32_matches_fp32_definition(size, frames):
 def test_hip_vit_f32_small_and_big_launch_forms_agree_bit_for_bit():
     """The per-layer GEMM has a 64-row form for launches that would leave most CUs empty (a few frames: what the reference's
     per-frame callers send) and the 128-row throughput form; both sum every output over k in the same order, so a frame's
-    tokens do not depend on how many frames share its launch: frames 0..1 alone (all four GEMMs in the small form), inside 20
+    tokens do not depend on how many frames share its launch: one or two frames alone (64-row form, residual GEMMs in the
+    32-row form of one-tile waves), inside 20
     frames (QKV and up + GELU big, the two residual GEMMs small) and inside 48 frames (all big) - identical bits."""
     from sslam_amd.vit_hip import HipViTF32
     _, mine = _hf_pair(2)
