@@ -12,7 +12,7 @@ allocation per frame, no host synchronisation (the caller reads what it wants fr
 of 8 (tokens in) / 72 (bf16 ViT inside) / 96 (fp32 ViT inside) library calls.  The C ABI was shaped for this (no allocation, no
 synchronisation, no host read-back inside the library; caller-owned workspace), and the replay is bit-identical - but MEASURED it
 buys nothing on this chip: 0.297 against 0.289 ms per frame with tokens in, 1.215 against 1.209 ms with the bf16 ViT inside,
-3.47 against 3.47 ms with the fp32 ViT (tools/online_probe.py).  At B = 1 the step is bound by the DURATION of its ~70 dependent
+2.12 against 2.11 ms with the fp32 ViT (tools/online_probe.py).  At B = 1 the step is bound by the DURATION of its ~70 dependent
 kernels (a frame is 7 row tiles: most launches occupy a few dozen of the 256 CUs for 5-20 us each), not by the host's launch rate -
 the host is already ahead of the device.  It is kept as an option because it takes the host out of the loop (0 library calls per
 frame), which matters to a caller that has other work for its CPU thread.
