@@ -214,9 +214,11 @@ __device__ __forceinline__ void rt_fill_vec(float *dst, const float *src, int nt
 // diagnostic build only (tools/rt_probe.py): shader-clock stamps of wave 0 per workgroup; never in the product build
 __device__ unsigned long long g_rt_probe[8 * 2048];
 #define RT_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define RT_WALL(var) const unsigned long long var = wall_clock64()          /* 100 MHz real-time counter: cycles / ticks = the shader clock */
 #define RT_ACC(dst, t1, t0) dst += (t1) - (t0)
 #else
 #define RT_STAMP(var)
+#define RT_WALL(var)
 #define RT_ACC(dst, t1, t0)
 #endif
 
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
     unsigned long long p_pro = 0, p_wait = 0, p_mma = 0, p_epi = 0;
 #endif
     RT_STAMP(t_begin);
+    RT_WALL(w_begin);
     typename Epi::State est;
     bf16x8 a[RT_KS];
     if (KC == 1) {            // one K chunk: the fragments are loaded once, before any accumulator is live
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rt_kernel(Pro pro, const bf16 *__
         unsigned long long *o = g_rt_probe + 8 * blockIdx.x;
         o[0] = __builtin_readcyclecounter() - t_begin;
         o[1] = p_pro; o[2] = p_wait; o[3] = p_mma; o[4] = p_epi;
+        o[6] = wall_clock64() - w_begin; o[7] = w_begin;
     }
 #endif
 }
@@ -633,6 +637,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(ProLN pro, const bf16
     unsigned long long p_pro = 0, p_wait = 0, p_mma = 0, p_epi = 0, p_gelu = 0;
 #endif
     RT_STAMP(t_begin);
+    RT_WALL(w_begin);
     bf16x8 a[RT_KS];
     pro.load(a, row0, 0, stg, vec_pro, lane, M);
     RT_STAMP(t_pro1);
@@ -754,6 +759,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(ProLN pro, const bf16
         const unsigned long long t_end = __builtin_readcyclecounter();
         o[0] = t_end - t_begin;
         o[1] = p_pro; o[2] = p_wait; o[3] = p_mma; o[4] = t_end - t_e0; o[5] = p_gelu;
+        o[6] = wall_clock64() - w_begin; o[7] = w_begin;
     }
 #endif
 }

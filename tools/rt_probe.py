@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 from sslam_amd import lib
+if os.environ.get("SSLAM_BENCH_SO"):            # a probe build kept beside the product library (tools/build_variant.sh)
+    lib.SO_PATH = os.path.abspath(os.environ["SSLAM_BENCH_SO"])
 L = lib.lib()
 if not hasattr(L, "sslam_probe_vit"):
     sys.exit("libsslam_hip.so was not built with -DSSLAM_RT_PROBE")
@@ -35,5 +37,10 @@ for stop, label in [(1, "QKV (ProLN, EpiQKV)"), (2, "o_proj (ProBf16, EpiResidua
         t = t[: (rows + 127) // 128]          # the fused kernel runs one workgroup per row tile; later entries are stale
     t = t[t[:, 0] > 0]
     print(f"{label}: {len(t)} workgroups")
+    life_us = t[:, 6] * 0.01
+    start_us = (t[:, 7] - t[:, 7].min()) * 0.01
+    span = (start_us + life_us).max()
+    print(f"   shader clock {t[:, 0].sum() / t[:, 6].sum() * 0.1:5.3f} GHz (cycles per 100 MHz tick inside a wave); workgroup life {life_us.mean():6.1f} us; "
+          f"launch span {span:7.1f} us; mean workgroups in flight {life_us.sum() / span:6.1f}")
     for i, nm in enumerate(names):
         print(f"   {nm:14s} {t[:, i].mean():10.0f} cycles ({100 * t[:, i].mean() / t[:, 0].mean():5.1f} %)   min {t[:, i].min():9.0f} max {t[:, i].max():9.0f}")
