@@ -81,6 +81,12 @@ python $ROOT/tools/gather_cost.py > $OUT/${TAG}_multi_rank_costs.txt 2>/dev/null
 python $ROOT/tools/halo_cost.py >> $OUT/${TAG}_multi_rank_costs.txt 2>/dev/null
 python $ROOT/tools/upload_sweep.py > $OUT/${TAG}_upload_sweep.txt 2>/dev/null
 python $ROOT/tools/upload_timeline.py 307 > $OUT/${TAG}_upload_timeline.txt 2>/dev/null
+echo "[9] round-4 additions: the drop-in backbone at the reference's batch sizes, the per-frame stepper, the 4-rank rehearsal"
+python $ROOT/tools/backbone_batch_sweep.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_backbone_batch_sweep.txt
+python $ROOT/tools/online_probe.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_online_stepper.txt
+python $ROOT/bench.py --gpus 4 --rehearse-shared-gpu --steps 2 --warmup 1 > $OUT/${TAG}_rehearsal_4ranks.json 2>/dev/null
+# (clock probes need probe builds: tools/build_variant.sh probe csrc/vit_f32.hip vit_f32.hip -DSSLAM_CLOCK_PROBE -> tools/vit_f32_probe.py;
+#  tools/build_variant.sh rtprobe csrc/vit.hip vit.hip -DSSLAM_RT_PROBE -> SSLAM_BENCH_SO=... tools/rt_probe.py 82)
 # every BASELINE configuration at its full per-GPU size (configs[2]: 2 965 frames; configs[3] / [4]: one GPU's share of the 4- / 8-GPU job)
 for wl in fr1_xyz_50 fr2_desk_1024kp synthetic_2048kp fr3_long_office_4gpu synthetic_2048kp_8gpu; do
   python $ROOT/bench.py --steps 5 --warmup 2 --workload $wl --no-cpu-baseline --no-vit --no-directory --sustain 5 > $OUT/${TAG}_bench_$wl.json 2>/dev/null
