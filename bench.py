@@ -468,6 +468,16 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             vit32_ms = e0.elapsed_time(e1)
+            # one frame at a time (the reference's callers): the few-frame forms of the fp32 GEMMs
+            x1 = pipe_32.preprocess(imgs[:1])
+            for _ in range(3):
+                pipe_32.vit_hip.forward_features(x1)
+            e0.record()
+            for _ in range(20):
+                pipe_32.vit_hip.forward_features(x1)
+            e1.record()
+            torch.cuda.synchronize()
+            vit32_b1_ms = e0.elapsed_time(e1) / 20
             # beside it: the eager torch evaluation of the same weights (rocBLAS / hipBLASLt fp32 GEMMs + torch ops) on a sample
             ne = min(n, 128)
             fchunk = max(1, min(32, (64 * 789) // (5 + grid * grid)))
@@ -498,6 +508,7 @@ def main():
                         "eager_torch_fp32": {"vit_frames_s": round(ne / (eager_ms * 1e-3), 1), "frames": ne,
                                              "vit_tflops": round(ne * vit_flop / (eager_ms * 1e-3) / 1e12, 1),
                                              "hip_fp32_vs_eager_tokens_rel_err": float(f"{rel_hip_eager:.3e}")},
+                        "vit_batch1_ms": round(vit32_b1_ms, 4),
                         "bf16_vs_fp32_tokens_rel_err": round(tok_rel, 5),
                         "bf16_vs_fp32_keypoint_set_agreement": round(kp_same, 4),
                         "bf16_vs_fp32_match_agreement": round(hit / max(tot, 1), 4), "frames": n, "pairs": n - 1,
