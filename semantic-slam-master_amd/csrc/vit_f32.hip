@@ -516,8 +516,21 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) float Ks[2][AKT * ALDK], Vs[2][AKT * FHD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     // XCD-aware order: workgroup b runs on XCD b % 8; the `subs` workgroups of one (frame, head) stay on one XCD (K / V in its L2)
-    const int b = blockIdx.x, chunk = b / (8 * subs), within = b % (8 * subs);
-    const int bh = chunk * 8 + within % 8, sub = within / 8;
+    // When the last workgroup of a (frame, head) has idle waves (T = 789: 25 query tiles = 6 x 4 + 1), those LIGHT workgroups are
+    // dealt after all full ones: a light workgroup takes as long as a full one while it shares its SIMDs with full ones, but loads
+    // the matrix pipe a quarter as much - interleaved (every 7th) they hold a seventh of the slots at a quarter of their capacity;
+    // at the end of the launch they run among themselves, one or two waves per SIMD, in half the time.
+    const int n_qt_ = (T + 31) / 32, heavy = (n_qt_ % AW) ? subs - 1 : subs, n_chunks = (nbh + 7) / 8;
+    int b = blockIdx.x, chunk, bh, sub;
+    if (b < n_chunks * 8 * heavy) {
+        chunk = b / (8 * heavy);
+        const int within = b % (8 * heavy);
+        bh = chunk * 8 + within % 8, sub = within / 8;
+    } else {
+        b -= n_chunks * 8 * heavy;
+        chunk = b / 8;
+        bh = chunk * 8 + b % 8, sub = heavy;
+    }
     if (bh >= nbh) return;
 #ifdef SSLAM_CLOCK_PROBE
     const unsigned long long pr_c0 = clock64(), pr_w0 = wall_clock64();
