@@ -137,7 +137,10 @@ class HipViTF32:
             raise lib.SslamHipError("MLP width must be 1536")
         self.vit, self.device = vit, torch.device(device)
         self._keep, self._rope = [], {}
-        self._ws, self._side, self.n_streams = [None, None], None, 2      # launch groups alternate between two streams
+        # launch groups on ONE stream: alternating them between two (as the bf16 HipViT does, where it gains 3-5 %) costs 3 % here -
+        # two groups in flight double the working set (1.6 GB against a 256 MB MALL) and the fp32 kernels have no idle pipe to fill
+        # (613 frames: 2 598 frames/s on one stream, 2 513 on two)
+        self._ws, self._side, self.n_streams = [None, None], None, 1
         self.w = lib.VitWeightsF32()
         f, pk = self._f32, self._packed
         self.w.patch_w, self.w.patch_b = f(vit.patch_embed.weight.reshape(384, 768)), f(vit.patch_embed.bias)
@@ -173,9 +176,9 @@ class HipViTF32:
         return max(1, (512 * 128) // (5 + (size // 16) ** 2))
 
     def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
-        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed).  Several launch groups alternate
-        between two side streams (one workspace each), as in HipViT.forward_features: one group's kernels fill the ramps and
-        tails of the other's; the caller's stream semantics are kept."""
+        """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), launch groups of `chunk` frames one after
+        the other on the caller's stream (n_streams = 2: alternating between two side streams as HipViT does - measured slower
+        here, see __init__); the caller's stream semantics are kept either way."""
         n, _, s, s2 = images.shape
         assert s == s2 and s % 16 == 0 and images.is_cuda
         g = s // 16
