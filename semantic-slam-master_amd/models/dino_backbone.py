@@ -34,7 +34,7 @@ class DinoBackbone(nn.Module):
         ViT runs on a GPU under no_grad:
           "fp32"  (default - a script run unchanged keeps the reference's numerics) the HIP ViT-S/16 with fp32 operands on the
                   fp32 matrix pipe (sslam_vit_forward_f32): the REFERENCE'S numerics for A1 (its timm model is fp32), within
-                  ~1e-6 relative of the eager torch evaluation at 2.2 x its rate;
+                  ~1e-6 relative of the eager torch evaluation at 2.3 x its rate (single frame: 1.8 ms against 4.9);
           "bf16"  the HIP ViT-S/16 with bf16 MFMA operands (fp32 accumulation, LayerNorm, softmax, residual): the throughput
                   form, 5 x the fp32 rate; tokens within rel 2.5e-2 / cos > 0.995 of the fp32 definition - keypoint and match
                   agreement with the fp32 path is MEASURED (tests/test_gpu_harness.py, bench.py
