@@ -234,7 +234,9 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")           # RCCL refuses two ranks on one GPU: the rehearsal stages through host memory
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            import datetime
+            # a rendezvous or collective that does not complete fails the run after 5 minutes instead of hanging it
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks", file=sys.stderr)
             sys.exit(2)
