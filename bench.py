@@ -80,26 +80,24 @@ def synth_sequence(n_total, lo, hi, h, w, grid, device, seed):
     return imgs, toks
 
 
-def cpu_baseline(imgs, toks, ssd, rsd, size, K, budget_s=12.0):
+def cpu_baseline(imgs, toks, ssd, rsd, size, K, cfg, budget_s=12.0):
     """The CPU oracle (oracle/sslam_oracle.c, a port of the reference's algorithm) timed on this host's cores on a
-    bounded sample of the same workload: extract every frame once + one match per consecutive pair."""
+    bounded sample of the same workload: extract every frame once + one match per consecutive pair (oracle_check.oracle_block
+    with A0 inside - the same function the parity gate runs).  Returns (the JSON object, the outputs of one timed run): the gate
+    compares those outputs with the GPU pass too, so what is timed is what is checked."""
     from oracle import ora
+    from oracle_check import oracle_block
     nthr = ora.host_threads()       # affinity mask capped by the cgroup CPU quota
     ora.set_num_threads(nthr)
-    grid = size // 16
+    kept = {}
 
     def run(n):
         t0 = time.perf_counter()
-        for i in range(n):
-            ora.resize_rgb(imgs[i], size)                                   # A0
-        feat = ora.bn_tokens(toks[:n])[0].reshape(n, grid, grid, 384)       # A2
-        sal = ora.selector_saliency(feat, ssd)                              # A3
-        kp, sc, idx, _ = ora.select_keypoints(sal, K)                       # A4/A5
-        desc = ora.refine(ora.gather(feat, kp), rsd)                        # A6/A7
-        inten = [ora.intensity(imgs[i], size, ora.patch_to_pixel(kp[i])) for i in range(n)]   # A9
-        for i in range(n - 1):
-            ora.match_with_quality(desc[i], desc[i + 1], sc[i], sc[i + 1], 0.3, 0.5, 0.7, inten[i], inten[i + 1], 0.15)  # M1
-        return time.perf_counter() - t0
+        o = oracle_block(imgs[:n], toks[:n], ssd, rsd, size, K, cfg, with_a0=True)
+        t = time.perf_counter() - t0
+        if n == len(imgs):
+            kept["out"] = o
+        return t
 
     run(4)                                       # warm-up: thread pool, page faults
     nmax = len(imgs)
@@ -117,7 +115,7 @@ def cpu_baseline(imgs, toks, ssd, rsd, size, K, budget_s=12.0):
                 median=round(nmax / float(np.median(ts)), 2),
                 sample=f"{nmax} frames of the same workload (each extracted once + {nmax - 1} consecutive-pair matches), "
                        f"repeated {len(ts)}x = {sum(ts):.1f} s of CPU work; oracle/sslam_oracle.c (AVX2+FMA, OpenMP) on "
-                       f"{nthr} threads; mean of repeats")
+                       f"{nthr} threads; mean of repeats"), kept["out"]
 
 
 def measured_mfma_peak():
@@ -143,6 +141,30 @@ def path_roofline(fps, grid, K, hidden, h, w):
     bytes_io = h * w * 3 + (5 + cells) * 384 * 4 + K * (8 + 4 + 4 + 512) + K * 20
     return {"flop_per_frame": flop, "mfma_tflops": round(fps * flop / 1e12, 2), "frac_of_fp32_matrix_peak": round(fps * flop / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
             "compulsory_bytes_per_frame": bytes_io, "hbm_tb_s": round(fps * bytes_io / 1e12, 3), "frac_of_hbm_8tb_s": round(fps * bytes_io / 8e12, 4)}
+
+
+def index_parity_vs_torch(grid):
+    """What is known about index parity against TORCH itself (the reference's own arithmetic) at this grid, read from the
+    committed measurement (tools/order_swap_rate.py on the reference goldens) - the bench line's bit_exact is against the oracle."""
+    import glob
+    src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_order_swap_rate.json")))
+    if grid <= 28:
+        return {"index_parity_vs_torch": {"level": "exact: keypoint indices and match pairs identical to the reference's on every G = 28 golden",
+                                          "source": "tests/golden/e2e.npz, selector.npz, select_wide.npz, match_wide.npz (tests/test_oracle_golden.py)"}}
+    level = {"level": "set-level: keypoint SET and matches as (cell, cell) pairs identical to the reference's; keypoint ORDER (hence raw match "
+                      "indices) only up to swaps between saliencies the reference itself holds closer than its conv's summation-order noise",
+             "source": "tests/e2e_check.py on tests/golden/e2e_g40.npz / e2e_g60.npz / order_g60.npz"}
+    if src:
+        try:
+            d = json.load(open(src[-1]))
+            key = "e2e_g40" if grid == 40 else "e2e_g60"
+            level["measured"] = {"fixture": key, **d[key]["summary"], "pairs": d[key]["pairs"],
+                                 "reference_vs_itself": {k: v for k, v in d.get("order_g60", {}).get("summary", {}).items() if k.startswith("reference_vs_itself")}}
+            level["source"] += "; profiles/" + os.path.basename(src[-1])
+        except Exception:
+            pass
+    return {"index_parity_vs_torch": level,
+            "note": "bit_exact is against the CPU oracle; against torch itself see index_parity_vs_torch (set-level at G >= 40)"}
 
 
 def launch_plan(gpus: int, env: dict, device_count: int, shared_gpu: bool = False):
@@ -189,6 +211,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=10.0, help="N = 1: seconds of back-to-back steps for the `sustained` rate (0: skip)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
+    ap.add_argument("--parity-frames", type=int, default=-1,
+                    help="frames per rank compared with the CPU oracle after the timed region (-1: the whole block at G = 28, "
+                         "258 frames in three blocks at the larger grids)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
     ap.add_argument("--no-vit-fp32", action="store_true", help="skip the fp32-operand HIP ViT leg (reference numerics for A1) of the ViT-inside pass")
     ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
@@ -207,6 +232,9 @@ def main():
                     help="functional rehearsal of the N-rank path on fewer than N GPUs: ranks share the visible GPU(s), torch.distributed "
                          "runs on gloo with device buffers staged through host memory, rank 0 checks sharded == single-process; "
                          "prints a line with value null (NOT a measurement)")
+    ap.add_argument("--test-corrupt-gathered", action="store_true",
+                    help="TEST ONLY (N > 1): flip one match index of the first cross-rank pair in the gathered result before the parity "
+                         "gate - the run must then report no value and exit 1")
     args = ap.parse_args()
 
     # nothing above this line and nothing in launch_plan touches a GPU (torch.cuda.device_count() only counts devices)
@@ -646,6 +674,80 @@ def main():
                     "matches_per_pair": round(float(cb.mean()), 1)}
         del pipe_b, ob
 
+    # ---- parity gate (every rank; outside the timed region) ------------------------------------------------------------
+    # The metric says "match-index bit-exact vs CPU ref": the last timed step's outputs are compared with the CPU oracle, bit for
+    # bit - keypoint indices, scores, descriptors, intensities of every checked frame, and for every checked pair the match count,
+    # the match pairs and the quality (visualize_matches_sequence.py:106-197 with the CLI thresholds :381-388, the pair loop
+    # :297-320).  N = 1: the WHOLE sequence where the oracle covers it in seconds (G = 28: 613 frames ~ 3 s on 16 threads), else
+    # --parity-frames frames in blocks from both ends and the middle.  N > 1: every rank checks ITS block the same way on its
+    # share of the host cores; rank 0 also regenerates the frames on either side of every shard boundary from the seed, runs
+    # the oracle on them and compares the boundary pairs' rows of the GATHERED result (the only pairs that exercise the halo),
+    # and compares a digest of every rank's local match arrays with the digest of that rank's rows in the gathered arrays
+    # (what arrived is what was computed).  Any mismatch on any rank: no value.
+    from oracle import ora
+    from oracle_check import blocks_for, check_pass, compare_block, oracle_block
+    ora.set_num_threads(max(1, ora.host_threads() // world))
+    want = args.parity_frames if args.parity_frames >= 0 else (n if grid <= 28 and n <= 1400 else 258)
+    tpar = time.perf_counter()
+    parity = check_pass(out, imgs, toks, ssd, rsd, size, K, cfg, blocks_for(n, want, cfg.spacing), frame0=lo)
+    parity["checked"] = "keypoint indices, scores, descriptors, intensities, match counts, match pairs, match quality"
+    parity["frames_total"], parity["pairs_total"] = n * world, n * world - cfg.spacing
+    if world > 1:
+        import hashlib
+
+        def digest(mt, q, c):
+            hsh = hashlib.sha256()
+            for t_ in (mt, q, c):
+                hsh.update(t_.contiguous().cpu().numpy().tobytes())
+            return hsh.hexdigest()
+
+        mine = dict(parity, rank=rank, digest=digest(out["matches"], out["quality"], out["match_count"]))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        if rank == 0:
+            sp_ = cfg.spacing
+            merged = dict(parity, frames_checked_vs_oracle=0, pairs_checked=0, matches_checked=0)
+            for pr in per_rank:
+                for k_ in ("frames_checked_vs_oracle", "pairs_checked", "matches_checked"):
+                    merged[k_] += pr[k_]
+                if not pr["bit_exact"]:
+                    merged["bit_exact"] = False
+                    merged["first_mismatch"] = merged["first_mismatch"] or f"rank {pr['rank']}: {pr['first_mismatch']}"
+            # boundary pairs of the gathered result against the oracle on regenerated frames
+            gm = {"matches": out["all_matches"], "quality": out["all_quality"], "match_count": out["all_match_count"]}
+            bpairs = bmatches = 0
+            if args.test_corrupt_gathered:
+                row_ = ranges[1][0] - sp_
+                gm["matches"][row_, 0, 1] = (gm["matches"][row_, 0, 1] + 1) % K
+            for r_ in range(1, world):
+                b_ = ranges[r_][0]
+                bi, bt = synth_sequence(n * world, b_ - sp_, b_ + sp_, h, w, grid, dev, seed=1234)
+                ob = oracle_block(bi.cpu().numpy(), bt.cpu().numpy(), ssd, rsd, size, K, cfg)
+                rows = {k_: v_[b_ - sp_:b_].cpu().numpy() for k_, v_ in gm.items()}
+                okb, _, np_, nm_, why = compare_block(ob, {}, rows, 0, K)
+                bpairs += np_
+                bmatches += nm_
+                if not okb:
+                    merged["bit_exact"] = False
+                    merged["first_mismatch"] = merged["first_mismatch"] or f"boundary of rank {r_} (frame {b_}): {why}"
+            # what arrived on rank 0 is what every rank computed
+            off_, same_rows = 0, True
+            for r_, pr in enumerate(per_rank):
+                np_r = out["pairs_per_rank"][r_]
+                same_rows = same_rows and digest(gm["matches"][off_:off_ + np_r], gm["quality"][off_:off_ + np_r],
+                                                 gm["match_count"][off_:off_ + np_r]) == pr["digest"]
+                off_ += np_r
+            if not same_rows:
+                merged["bit_exact"] = False
+                merged["first_mismatch"] = merged["first_mismatch"] or "gathered rows differ from a rank's local match arrays"
+            merged.update(boundary_pairs_checked=bpairs, boundary_matches_checked=bmatches, boundaries=world - 1,
+                          gathered_rows_equal_every_ranks_local_result=same_rows, ranks_checked=world)
+            merged["pairs_checked"] += bpairs
+            merged["matches_checked"] += bmatches
+            parity = merged
+    parity["seconds"] = round(time.perf_counter() - tpar, 2)
+    parity["oracle_threads"] = ora.num_threads()
+
     if rank == 0:
         # per step: a sharded step extracts in two launch groups (boundary frames first), so sum the launches of a stage
         stage_ms = {k: round(float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps, 4) for k, v in ev.items()}
@@ -668,40 +770,7 @@ def main():
                                " (FETCH_SIZE / WRITE_SIZE passes of the same command, gfx950 corrections applied)")
             except Exception:
                 traffic = traffic_src = None
-        # parity gate against the oracle on the first frames and the pairs between them (outside the timed region):
-        # keypoint indices, descriptors, intensities bit-equal; match pairs equal and quality bit-equal - the metric says
-        # "match-index bit-exact vs CPU ref", so the matches themselves are compared (visualize_matches_sequence.py:106-197
-        # with the CLI thresholds :381-388)
-        from oracle import ora
-        nchk = min(3, n)
-        o_feat = ora.bn_tokens(toks[:nchk].cpu().numpy())[0].reshape(nchk, grid, grid, 384)
-        o_kp, o_sc, o_idx, _ = ora.select_keypoints(ora.selector_saliency(o_feat, ssd), K)
-        o_desc = ora.refine(ora.gather(o_feat, o_kp), rsd)
-        imgs_h = imgs[:nchk].cpu().numpy()
-        o_int = np.stack([ora.intensity(imgs_h[i], size, ora.patch_to_pixel(o_kp[i])) for i in range(nchk)])
-        ok = bool(np.array_equal(out["idx"][:nchk].cpu().numpy(), o_idx) and
-                  np.array_equal(out["descriptors"][:nchk].cpu().numpy().view(np.uint32), o_desc.view(np.uint32)) and
-                  np.array_equal(out["intensity"][:nchk].cpu().numpy().view(np.uint32), o_int.view(np.uint32)))
-        pairs_checked = matches_checked = 0
-        g_mt, g_q, g_cnt = out["matches"].cpu().numpy(), out["quality"].cpu().numpy(), out["match_count"].cpu().numpy()
-        for p_ in range(0, nchk - cfg.spacing):
-            omt, oq = ora.match_with_quality(o_desc[p_], o_desc[p_ + cfg.spacing], o_sc[p_], o_sc[p_ + cfg.spacing], cfg.saliency_weight,
-                                             cfg.min_saliency, cfg.min_descriptor_sim, o_int[p_], o_int[p_ + cfg.spacing], cfg.min_intensity)
-            c = int(g_cnt[p_])
-            ok = ok and c == len(omt) and bool(np.array_equal(g_mt[p_, :c], omt)) and \
-                bool(np.array_equal(g_q[p_, :c].view(np.uint32), oq.view(np.uint32)))
-            pairs_checked += 1
-            matches_checked += len(omt)
-        parity_note = None
-        if grid >= 40:
-            parity_note = ("against the ORACLE everything above is bit-exact.  Against torch itself (reference goldens, tests/e2e_check.py, "
-                           "profiles/r04_order_swap_rate.json): keypoint SET identical in 56 / 56 frames; keypoint ORDER at G = 60 / K = 2048 "
-                           "identical in 10 of 48 frames, else 3.8 of 2048 positions (0.19 %) swapped between saliencies <= 1.8e-6 apart; "
-                           "at G = 40 / K = 1024 identical in 7 of 8 frames (one 2-position swap, gap 3e-8); all 25 match sets "
-                           "(30 417 matches) identical as (cell, cell) pairs, as raw indices only where both frames kept their order "
-                           "(8 / 8 at G = 40, 0 / 17 at G = 60).  The reference run against ITSELF with 1 intra-op thread instead of 4 "
-                           "reorders 22 of 32 G = 60 frames (2.5 positions on average): the order among near-ties is a property of "
-                           "torch's conv summation order, not of the algorithm")
+        ok = bool(parity["bit_exact"])
         rehearse = None
         if rehearsal:
             # the whole sequence in ONE process on this GPU: the gathered result of the sharded run must equal it pair for pair
@@ -737,9 +806,7 @@ def main():
             # SURVEY 8d path-level figures: authored-path FLOP (A3 + A7 + A6 + one M1 per frame) and compulsory bytes per frame
             "path_roofline": path_roofline(n * world * args.steps / dt, grid, K, pipe.selector.hidden, h, w),
             "stage_ms": stage_ms,
-            "parity": {"frames_checked_vs_oracle": nchk, "pairs_checked": pairs_checked, "matches_checked": matches_checked,
-                       "checked": "keypoint indices, descriptors, intensities, match pairs, match quality", "bit_exact": ok,
-                       **({"note": parity_note} if parity_note else {})},
+            "parity": dict(parity, bit_exact=ok, **index_parity_vs_torch(grid)),
             "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "frame_ranges": ranges,
             "matches_per_pair": round(float(out["match_count"].float().mean().item()), 1),
         }
@@ -756,7 +823,16 @@ def main():
         if dir_leg is not None:
             res["tum_directory"] = dir_leg
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(imgs[:64].cpu().numpy(), toks[:64].cpu().numpy(), ssd, rsd, size, K)
+            nb = min(n, 64)
+            res["cpu_baseline"], cb_out = cpu_baseline(imgs[:nb].cpu().numpy(), toks[:nb].cpu().numpy(), ssd, rsd, size, K, cfg)
+            # what was timed is what is checked: the timed run's own outputs against the GPU pass (frames 0..63, pairs 0..62)
+            okc, _, pc, mc, whyc = compare_block(cb_out, {k_: out[k_][:nb].cpu().numpy() for k_ in ("idx", "scores", "descriptors", "intensity")},
+                                                 {k_: out[k_][:nb - cfg.spacing].cpu().numpy() for k_ in ("matches", "quality", "match_count")}, 0, K)
+            res["cpu_baseline"]["timed_outputs_equal_gpu_pass"] = {"bit_exact": okc, "frames": nb, "pairs": pc, "matches": mc, "first_mismatch": whyc}
+            if not okc:
+                ok = False
+                res["parity"]["bit_exact"] = False
+                res["parity"]["first_mismatch"] = res["parity"].get("first_mismatch") or f"cpu_baseline outputs: {whyc}"
         if rehearse is not None:
             res["rehearsal"], res["value"] = rehearse, None
             res["parallelism_backend"] = "gloo (rehearsal)"

@@ -361,9 +361,32 @@ def test_two_rank_rehearsal_on_one_gpu(T):
     d = json.loads(line)
     assert d["value"] is None and d["n_gpus"] == 2 and d["n_ranks_seen"] == 2
     assert d["frame_ranges"] == [[0, 21], [21, 42]]
-    assert d["parity"]["bit_exact"] and d["parity"]["pairs_checked"] == 2
+    # the gate of an N-rank line: every rank's whole block against the oracle (21 frames, 20 pairs inside each), the pair that crosses
+    # the shard boundary (frames 20 | 21, regenerated on rank 0 from the seed) against the oracle through the GATHERED arrays, and the
+    # gathered rows of every rank against a digest of what that rank computed
+    par = d["parity"]
+    assert par["bit_exact"] and par["first_mismatch"] is None
+    assert par["ranks_checked"] == 2 and par["frames_checked_vs_oracle"] == 42
+    assert par["boundaries"] == 1 and par["boundary_pairs_checked"] == 1 and par["boundary_matches_checked"] > 0
+    assert par["pairs_checked"] == 41 and par["pairs_total"] == 41 and par["gathered_rows_equal_every_ranks_local_result"]
     reh = d["rehearsal"]
     assert reh["sharded_equals_single_process"] and reh["pairs"] == 41 and reh["pairs_per_rank"] == [21, 20] and reh["matches"] > 0
+
+
+def test_rehearsal_gate_refuses_a_corrupted_boundary_pair(T):
+    """The same rehearsal with ONE match index of the cross-rank pair flipped in the gathered result before the gate: no value,
+    exit code 1, and the mismatch is attributed to the boundary (the rank-0-local check of round 4 would not have seen it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--frames", "9",
+                        "--steps", "1", "--warmup", "1", "--test-corrupt-gathered"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["value"] is None and not d["parity"]["bit_exact"]
+    assert "boundary of rank 1" in d["parity"]["first_mismatch"] or "gathered rows" in d["parity"]["first_mismatch"]
 
 
 _RCCL_ONE_RANK = r'''
