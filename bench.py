@@ -316,8 +316,8 @@ def main():
         for a_ in range(0, t.shape[0], step_):
             tt, ii = t[a_:a_ + step_], im[a_:a_ + step_]
             og = {k_: v_[a_:a_ + step_] for k_, v_ in o.items()}
-            vit_in = timed("A0_preprocess", lambda: pipe.preprocess(ii))
-            feat = timed("A2_bn_tokens", lambda: pipe.features(tt))
+            vit_in = timed("A0_preprocess", lambda: pipe.preprocess(ii, reuse=True))
+            feat = timed("A2_bn_tokens", lambda: pipe.features(tt, reuse=True))
             ws = pipe.workspace(tt.shape[0], 0)
             timed("A3_selector_saliency", lambda: lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden, out=og["saliency"], workspace=ws))
             timed("A45_select_keypoints",
@@ -485,12 +485,14 @@ def main():
         if not args.no_vit_fp32:
             vit_mod = pipe_v.vit_hip.vit
             pipe_32 = SequencePipeline(cfg, ssd, rsd, device=dev, vit=vit_mod, vit_precision="fp32")     # sslam_vit_forward_f32
-            pipe_32.run(imgs[:min(n, 64)])
+            pipe_32.run(imgs)                          # warm-up at the full size: workspaces, the fp32 image buffer, the output buffers
             torch.cuda.synchronize()
             t32 = time.perf_counter()
-            o32 = pipe_32.run(imgs)
+            n32 = max(1, min(args.steps, 2))
+            for _ in range(n32):
+                o32 = pipe_32.run(imgs)
             torch.cuda.synchronize()
-            dt32 = time.perf_counter() - t32
+            dt32 = (time.perf_counter() - t32) / n32
             tok32 = pipe_32.tokens_from_images(imgs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -674,6 +676,68 @@ def main():
                     "matches_per_pair": round(float(cb.mean()), 1)}
         del pipe_b, ob
 
+    # additional legs (N > 1), reported beside `value` so that a scaling curve shows WHAT bounds it (SURVEY 8e expects the host-side
+    # feed and the rank-0 gather, not xGMI): (a) every rank feeds ITS block from pinned host memory (chunked H2D on a side stream
+    # under the extraction, harness.run_frames) - all ranks at once, so the host's PCIe lanes and cores are shared as they would
+    # be; a per-rank local pass (no halo, no gather); (b) the sharded step with the HIP ViT inside (images -> A0 -> A1 -> ... -> M1,
+    # halo + gather included).  Same bracket as `value`: barrier + synchronize on both sides, MAX over ranks.
+    multi_legs = None
+    if world > 1 and not (args.no_upload and args.no_vit):
+        multi_legs = {}
+
+        def rank_max(x):
+            tt_ = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            return float(tt_.item())
+
+        nl = max(1, min(args.steps, 3))
+        if not args.no_upload:
+            from sslam_amd.harness import run_frames
+            imgs_pin = imgs.cpu().pin_memory()
+            kw_u = dict(spacings=(cfg.spacing,), tokens=toks, pinned_source=imgs_pin, preprocess_too=True)
+            run_frames(pipe, n, h, w, **kw_u)
+            fence()
+            tu = time.perf_counter()
+            for _ in range(nl):
+                ou = run_frames(pipe, n, h, w, **kw_u)
+            fence()
+            dtu = rank_max((time.perf_counter() - tu) / nl)
+            npl = n - cfg.spacing
+            same_u = bool(torch.equal(ou[cfg.spacing]["matches"], out["matches"][:npl]) and
+                          torch.equal(ou[cfg.spacing]["match_count"], out["match_count"][:npl]) and
+                          torch.equal(ou["frames"]["descriptors"], out["descriptors"]))
+            same_u = rank_max(0.0 if same_u else 1.0) == 0.0
+            multi_legs["with_upload"] = {"value": round(n * world / dtu, 2), "unit": "frames/s", "ms_per_step": round(dtu * 1e3, 3),
+                                         "frac_of_resident_value": round((n * world / dtu) / (n * world * args.steps / dt), 4),
+                                         "what": "every rank: pinned host uint8 frames of ITS block -> chunked H2D on a side stream under A0..A9 + M1 "
+                                                 "(tokens resident, as in `value`); all ranks concurrently; per-rank local pass (no halo, no gather)",
+                                         "equal_to_resident_pass_on_every_rank": same_u}
+            del ou, imgs_pin
+        if not args.no_vit:
+            from sslam_amd.vit import DinoV3ViT
+            torch.manual_seed(0)                              # every rank builds the same random DINOv3-architecture weights
+            pipe_v = SequencePipeline(cfg, ssd, rsd, device=dev, vit=DinoV3ViT().to(dev).eval())
+
+            def extract_v(_t, im, out=None):
+                return pipe_v.extract(pipe_v.tokens_from_images(im), im, out=out)
+
+            runner_v = ShardedSequenceRunner(extract_v, pipe_v.match, spacing=cfg.spacing, alloc_fn=lambda rows: pipe_v.alloc_extract(rows, True),
+                                             halo=args.halo)
+            step_v = lambda: runner_v.run(toks, imgs, gather=args.gather, frames_per_rank=frames_per_rank)      # noqa: E731
+            step_v()
+            fence()
+            tv_ = time.perf_counter()
+            for _ in range(nl):
+                ov_ = step_v()
+            fence()
+            dtv_ = rank_max((time.perf_counter() - tv_) / nl)
+            multi_legs["with_vit"] = {"value": round(n * world / dtv_, 2), "unit": "frames/s", "ms_per_step": round(dtv_ * 1e3, 3),
+                                      "what": "the sharded step with the HIP ViT inside: images -> A0 -> bf16 HIP ViT-S/16 (random DINOv3-architecture "
+                                              "weights, the same on every rank) -> A2..A9 -> M1, halo exchange and gather to rank 0 included",
+                                      "pairs_gathered_on_rank0": int(ov_["all_match_count"].shape[0]) if rank == 0 else None,
+                                      "matches_per_pair": round(float(ov_["match_count"].float().mean().item()), 1)}
+            del ov_, pipe_v, runner_v
+
     # ---- parity gate (every rank; outside the timed region) ------------------------------------------------------------
     # The metric says "match-index bit-exact vs CPU ref": the last timed step's outputs are compared with the CPU oracle, bit for
     # bit - keypoint indices, scores, descriptors, intensities of every checked frame, and for every checked pair the match count,
@@ -840,6 +904,8 @@ def main():
             res["parallelism_backend"] = "nccl (RCCL)"
         if world > 1:
             res["gather"], res["halo"] = args.gather, args.halo
+            if multi_legs:
+                res.update(multi_legs)
         if not ok and rehearse is None:
             # the metric says "match-index bit-exact vs CPU ref": a run that is not, reports no value and fails
             res["value_unverified"], res["value"] = res["value"], None

@@ -269,7 +269,8 @@ int sslam_vit_forward_patches(const void *patches_bf16, int n_frames, int size, 
  * size); bqkv has zeros for the k rows; patch_w is the Conv2d weight viewed as (384, 768), as it is; prefix, rope_cos / rope_sin
  * as in sslam_vit_weights_t - DINOv3's construction, the 32 angles of a cell tiled twice: columns d and d + 32 of a row are equal
  * and this entry reads columns 0..31 only (a caller with other tables must not use it; sslam_amd/vit_hip.py checks).
- * Workspace: sslam_vit_f32_workspace_bytes(n_frames, size) bytes (x, LayerNorm output, q / k / v, MLP hidden: 13.7 KB per token). */
+ * Workspace: sslam_vit_f32_workspace_bytes(n_frames, size) bytes (x, LayerNorm output, q / k / v, MLP hidden: 13.7 KB per token;
+ * for n_frames <= SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES also the key-split attention's partials, 7.9 KB per token). */
 typedef struct {
     const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ls1, *ln2_g, *ln2_b, *wup, *bup, *wdown, *bdown, *ls2;
 } sslam_vit_layer_f32_t;
@@ -284,6 +285,23 @@ int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_in, float *o
 long long sslam_vit_f32_workspace_bytes(int n_frames, int size);
 int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *weights_host_struct,
                           void *workspace, long long workspace_bytes, float *tokens_out, void *stream);
+/* The same forward with the attention's launch form named by the caller.  The reference's callers run the backbone at B = 1
+ * (visualize_matches_sequence.py:72-74) and B = 4 (train.py:300-302): a launch of a few frames leaves most of the chip idle
+ * while 42 workgroups per frame walk all key tiles one after the other.  attention_form:
+ *   SSLAM_ATTN_ONE_PASS  (0) one workgroup per (frame, head, 128 queries) over all keys - the throughput form;
+ *   SSLAM_ATTN_KEY_SPLIT (1) five workgroups per (frame, head, 128 queries), one contiguous key range each, un-normalised
+ *                            partials (O, running maximum, row sum) in the workspace, merged in the fixed order 0..4 by a second
+ *                            launch: deterministic, independent of the batch, ~1e-6 relative from the one-pass form (another
+ *                            summation order of the same softmax); n_frames <= SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES, else
+ *                            SSLAM_E_INVALID (the workspace holds the partials only up to that size).
+ * sslam_vit_forward_f32 is this entry with form = KEY_SPLIT when n_frames <= SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES, else ONE_PASS; a
+ * caller that cuts one batch into several launches passes the form of the WHOLE batch to each, so that a frame's tokens do not
+ * depend on where the cuts fall (sslam_amd/vit_hip.py does). */
+#define SSLAM_ATTN_ONE_PASS 0
+#define SSLAM_ATTN_KEY_SPLIT 1
+#define SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES 8
+int sslam_vit_forward_f32_form(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *weights_host_struct,
+                               void *workspace, long long workspace_bytes, float *tokens_out, int attention_form, void *stream);
 
 #ifdef __cplusplus
 }

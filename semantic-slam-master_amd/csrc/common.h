@@ -33,6 +33,7 @@ enum sslam_knob_id {
     KNOB_CONVBF_VARIANT,      // SSLAM_CONVBF_VARIANT
     KNOB_VIT_NO_FUSED_MLP,    // SSLAM_VIT_NO_FUSED_MLP    the two-launch MLP
     KNOB_BN_FORM,             // SSLAM_BN_FORM             1: three-sweep BatchNorm kernel instead of the register-resident one
+    KNOB_VIT_F32_NO_KEY_SPLIT,// SSLAM_VIT_F32_NO_KEY_SPLIT the one-pass attention also for launches of a few frames
     KNOB_RT_STOP,             // SSLAM_RT_STOP             probe builds only
     KNOB_COUNT
 };

@@ -12,7 +12,7 @@ long long g_knob_at_load[KNOB_COUNT];   // what the environment said when the li
 const char *const kKnobNames[KNOB_COUNT] = {
     "SSLAM_M1_VARIANT",   "SSLAM_CONV_VARIANT",  "SSLAM_CONV_LATENCY_ROWS", "SSLAM_CONV_LAT2_ROWS",   "SSLAM_CONV_NO_HALO",
     "SSLAM_CONV_TAIL",    "SSLAM_CONVBF_NO_HALO", "SSLAM_CONVBF_TAIL",      "SSLAM_CONVBF_VARIANT",   "SSLAM_VIT_NO_FUSED_MLP",
-    "SSLAM_BN_FORM",      "SSLAM_RT_STOP"};
+    "SSLAM_BN_FORM",      "SSLAM_VIT_F32_NO_KEY_SPLIT", "SSLAM_RT_STOP"};
 // the ONE place the environment is read: when the library is loaded
 struct KnobInit {
     KnobInit() {

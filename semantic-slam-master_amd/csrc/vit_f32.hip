@@ -511,8 +511,19 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ unsigned long long g_probe_attn_f32[4 * 8192];
 #endif
 constexpr int AW = 4, AKT = 32, ALDK = 68;      // waves per workgroup (4 x 32 queries; one wave per SIMD and workgroup), keys per tile
+// KEY-SPLIT FORM (SPLIT = true; launches of a few frames - the reference's own callers run the backbone at B = 1 and B = 4,
+// visualize_matches_sequence.py:72-74, train.py:300-302): one frame is 6 heads x 7 workgroups = 42 workgroups walking 25 key tiles one
+// after the other - 62 us per layer on 42 of 256 CUs.  Here a workgroup takes ONE of ASPLIT contiguous key ranges (ASPLIT a
+// compile-time constant, the ranges a function of T only) and leaves its un-normalised partial (O, m, l) per query in the workspace;
+// attn_f32_merge_kernel combines the partials in the fixed order split 0 .. ASPLIT - 1.  The result is deterministic and a
+// frame's tokens still do not depend on what else is in the launch - but they differ from the one-pass form's in the last bits
+// (another summation order of the same softmax), so a launch of <= ASPLIT_MAX_FRAMES frames and a larger one agree to ~1e-6
+// relative, not bit for bit (A1's bar is 1e-4 against the eager evaluation).
+constexpr int ASPLIT = 5, ASPLIT_MAX_FRAMES = 8;
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-                                                            float *__restrict__ y, int T, int nbh, int subs) {
+                                                            float *__restrict__ y, int T, int nbh, int subs, float *__restrict__ part_o,
+                                                            float *__restrict__ part_ml) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AKT * ALDK], Vs[2][AKT * FHD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     // XCD-aware order: workgroup b runs on XCD b % 8; the `subs` workgroups of one (frame, head) stay on one XCD (K / V in its L2)
@@ -520,16 +531,23 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
     // dealt after all full ones: a light workgroup takes as long as a full one while it shares its SIMDs with full ones, but loads
     // the matrix pipe a quarter as much - interleaved (every 7th) they hold a seventh of the slots at a quarter of their capacity;
     // at the end of the launch they run among themselves, one or two waves per SIMD, in half the time.
-    const int n_qt_ = (T + 31) / 32, heavy = (n_qt_ % AW) ? subs - 1 : subs, n_chunks = (nbh + 7) / 8;
-    int b = blockIdx.x, chunk, bh, sub;
-    if (b < n_chunks * 8 * heavy) {
-        chunk = b / (8 * heavy);
-        const int within = b % (8 * heavy);
-        bh = chunk * 8 + within % 8, sub = within / 8;
+    int bh, sub, split = 0;
+    if constexpr (SPLIT) {
+        // a few hundred workgroups at most: the hardware deals them round-robin over the XCDs and their CUs, one per CU
+        const int b = blockIdx.x;
+        split = b % ASPLIT, sub = (b / ASPLIT) % subs, bh = b / (ASPLIT * subs);
     } else {
-        b -= n_chunks * 8 * heavy;
-        chunk = b / 8;
-        bh = chunk * 8 + b % 8, sub = heavy;
+        const int n_qt_ = (T + 31) / 32, heavy = (n_qt_ % AW) ? subs - 1 : subs, n_chunks = (nbh + 7) / 8;
+        int b = blockIdx.x, chunk;
+        if (b < n_chunks * 8 * heavy) {
+            chunk = b / (8 * heavy);
+            const int within = b % (8 * heavy);
+            bh = chunk * 8 + within % 8, sub = within / 8;
+        } else {
+            b -= n_chunks * 8 * heavy;
+            chunk = b / 8;
+            bh = chunk * 8 + b % 8, sub = heavy;
+        }
     }
     if (bh >= nbh) return;
 #ifdef SSLAM_CLOCK_PROBE
@@ -574,17 +592,31 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
 #pragma unroll
     for (int e = 0; e < 16; e++) o[0][e] = o[1][e] = sc[e] = 0.0f;
     float m = -1.0e30f, l = 0.0f;
-    const int n_kt = (T + AKT - 1) / AKT;
-    // prologue: K(0), V(0), K(1) in LDS; S^T of tile 0
-    fetch_k(0);
-    fetch_v(0);
-    stash_k(0);
-    stash_v(0);
-    fetch_k(min(1, n_kt - 1) * AKT);
-    stash_k(1);
+    // key tiles [kt0, n_kt) of this workgroup: all of them, or the split's range (ceil(tiles / ASPLIT) each; a range past the end is empty)
+    const int n_kt_all = (T + AKT - 1) / AKT, kt_per = SPLIT ? (n_kt_all + ASPLIT - 1) / ASPLIT : n_kt_all;
+    const int kt0 = split * kt_per, n_kt = min(n_kt_all, kt0 + kt_per);
+    if constexpr (SPLIT) {
+        if (kt0 >= n_kt) {              // nothing to do: an empty partial (weight exp2(-1e30 - M) = 0 in the merge)
+            const int qe = (sub * AW + wave) * 32 + r;
+            if (qe < T && h == 0) {
+                float *po = part_o + (((long long)split * nbh + bh) * T + qe) * FHD;
+                for (int d = 0; d < FHD; d += 4) *reinterpret_cast<float4 *>(po + d) = make_float4(0.f, 0.f, 0.f, 0.f);
+                float *pm = part_ml + (((long long)split * nbh + bh) * T + qe) * 2;
+                pm[0] = -1.0e30f, pm[1] = 0.0f;
+            }
+            return;
+        }
+    }
+    // prologue: K(kt0), V(kt0), K(kt0 + 1) in LDS; S^T of tile kt0 (buffers by tile parity, as in the loop)
+    fetch_k(kt0 * AKT);
+    fetch_v(kt0 * AKT);
+    stash_k(kt0 & 1);
+    stash_v(kt0 & 1);
+    fetch_k(min(kt0 + 1, n_kt - 1) * AKT);
+    stash_k((kt0 + 1) & 1);
     __syncthreads();
     if (wave_on) {
-        const float *A = &Ks[0][r * ALDK + 4 * h];
+        const float *A = &Ks[kt0 & 1][r * ALDK + 4 * h];
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(A + 8 * g);
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
             for (int st = 0; st < 4; st++) sc = mfma32(a[st], qreg[4 * g + st], sc);
         }
     }
-    __syncthreads();          // iteration 0 overwrites Ks[0]
+    __syncthreads();          // the first iteration overwrites Ks[kt0 & 1]
     float vf0[16], vf1[16];
 #define ATT_SLICE_MAX()                                                                                               \
     {                                                                                                                 \
@@ -613,7 +645,7 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
     }
 #define ATT_VREADS(dst_, off_, e0_)                                                                                   \
     _Pragma("unroll") for (int e = (e0_); e < (e0_) + 8; e++) dst_[e] = V[crow(e, h) * FHD + (off_) + r];
-    for (int kt = 0; kt + 1 < n_kt; kt++) {
+    for (int kt = kt0; kt + 1 < n_kt; kt++) {
         const int kb = (kt + 1) & 1, vb = kt & 1;
         fetch_k(min(kt + 2, n_kt - 1) * AKT);          // unconditional and pinned here: see gemm_f32_kernel
         fetch_v((kt + 1) * AKT);
@@ -730,6 +762,20 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
 #undef ATT_MMA_S
     if (qt * 32 + r >= T) return;
     l += __shfl_xor(l, 32);
+    if constexpr (SPLIT) {
+        // the partial as it stands: O un-normalised, the running maximum (exp2 domain) and the row sum
+        float *po = part_o + (((long long)split * nbh + bh) * T + qt * 32 + r) * FHD + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4 *>(po + 32 * dt + 8 * g) = make_float4(o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]);
+        if (h == 0) {
+            float *pm = part_ml + (((long long)split * nbh + bh) * T + qt * 32 + r) * 2;
+            pm[0] = m, pm[1] = l;
+        }
+        return;
+    }
     const float inv = 1.0f / l;
     const int frame = bh / FH, head = bh % FH;
     float *dst = y + ((long long)frame * T + qt * 32 + r) * FD + head * FHD + 4 * h;
@@ -745,6 +791,35 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
             t.w = o[dt][4 * g + 3] * inv;
             *reinterpret_cast<float4 *>(dst + 32 * dt + 8 * g) = t;
         }
+}
+// partials of the key-split form -> y (n, T, 384): M = max m_s, O = sum_s 2^(m_s - M) O_s, l = sum_s 2^(m_s - M) l_s in the order
+// s = 0 .. ASPLIT - 1, y = O * (1 / l).  One thread per (frame-head, query, 4 consecutive d).
+__global__ __launch_bounds__(256) void attn_f32_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                            float *__restrict__ y, int T, int nbh) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)nbh * T * 16;
+    if (i >= total) return;
+    const int d4 = (int)(i & 15);
+    const long long row = i >> 4;                         // bh * T + t
+    const int bh = (int)(row / T), t = (int)(row % T);
+    float ms[ASPLIT], ls[ASPLIT], M = -1.0e30f;
+#pragma unroll
+    for (int sp = 0; sp < ASPLIT; sp++) {
+        const float2 ml = *reinterpret_cast<const float2 *>(part_ml + ((long long)sp * nbh * T + row) * 2);
+        ms[sp] = ml.x, ls[sp] = ml.y;
+        M = fmaxf(M, ml.x);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float l = 0.0f;
+#pragma unroll
+    for (int sp = 0; sp < ASPLIT; sp++) {
+        const float wgt = __builtin_amdgcn_exp2f(ms[sp] - M);
+        const float4 o = *reinterpret_cast<const float4 *>(part_o + ((long long)sp * nbh * T + row) * FHD + 4 * d4);
+        acc.x = fmaf(wgt, o.x, acc.x), acc.y = fmaf(wgt, o.y, acc.y), acc.z = fmaf(wgt, o.z, acc.z), acc.w = fmaf(wgt, o.w, acc.w);
+        l = fmaf(wgt, ls[sp], l);
+    }
+    const float inv = 1.0f / l;
+    const int frame = bh / FH, head = bh % FH;
+    *reinterpret_cast<float4 *>(y + ((long long)frame * T + t) * FD + head * FHD + 4 * d4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 #ifdef SSLAM_CLOCK_PROBE
 }  // namespace
@@ -774,12 +849,25 @@ extern "C" int sslam_vit_f32_pack_linear_host(const float *w, int n_out, int k_i
 extern "C" long long sslam_vit_f32_workspace_bytes(int n_frames, int size) {
     if (n_frames <= 0 || size <= 0 || size % FPATCH) return SSLAM_E_INVALID;
     const long long G = size / FPATCH, T = G * G + FPREFIX, rows = (long long)n_frames * T;
-    return (long long)(ws_align(rows * FD * 4) * 2 + ws_align(rows * FD * 4 * 3) + ws_align(rows * FMLP * 4));   // x, y, qkv, hidden
+    long long b = (long long)(ws_align(rows * FD * 4) * 2 + ws_align(rows * FD * 4 * 3) + ws_align(rows * FMLP * 4));   // x, y, qkv, hidden
+    if (n_frames <= ASPLIT_MAX_FRAMES)           // the key-split attention's partials: ASPLIT x (O, (m, l)) per (frame, head, query)
+        b += (long long)(ws_align(ASPLIT * rows * FD * 4) + ws_align(ASPLIT * rows * FH * 2 * 4));
+    return b;
 }
 
 extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *w, void *workspace,
                                      long long workspace_bytes, float *tokens_out, void *stream) {
+    const bool few = n_frames <= ASPLIT_MAX_FRAMES && sslam_knob(KNOB_VIT_F32_NO_KEY_SPLIT, 0) == 0;
+    return sslam_vit_forward_f32_form(images_chw, n_frames, size, w, workspace, workspace_bytes, tokens_out,
+                                      few ? SSLAM_ATTN_KEY_SPLIT : SSLAM_ATTN_ONE_PASS, stream);
+}
+
+extern "C" int sslam_vit_forward_f32_form(const float *images_chw, int n_frames, int size, const sslam_vit_weights_f32_t *w, void *workspace,
+                                          long long workspace_bytes, float *tokens_out, int attention_form, void *stream) {
+    static_assert(ASPLIT_MAX_FRAMES == SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES, "header and kernel disagree");
     if (!images_chw || !w || !workspace || !tokens_out || n_frames <= 0 || size <= 0 || size % FPATCH) return SSLAM_E_INVALID;
+    if (attention_form != SSLAM_ATTN_ONE_PASS && attention_form != SSLAM_ATTN_KEY_SPLIT) return SSLAM_E_INVALID;
+    if (attention_form == SSLAM_ATTN_KEY_SPLIT && n_frames > ASPLIT_MAX_FRAMES) return SSLAM_E_INVALID;
     if (workspace_bytes < sslam_vit_f32_workspace_bytes(n_frames, size)) return SSLAM_E_INVALID;
     if (((uintptr_t)images_chw | (uintptr_t)workspace | (uintptr_t)tokens_out) & 15) return SSLAM_E_INVALID;
     const int G = size / FPATCH, cells = G * G, T = cells + FPREFIX;
@@ -792,7 +880,9 @@ extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int 
     float *x = (float *)p;    p += ws_align(rows * FD * 4);
     float *y = (float *)p;    p += ws_align(rows * FD * 4);
     float *q = (float *)p, *k = q + rows * FD, *v = k + rows * FD;    p += ws_align(rows * FD * 4 * 3);
-    float *hid = (float *)p;
+    float *hid = (float *)p;  p += ws_align(rows * FMLP * 4);
+    const bool split = attention_form == SSLAM_ATTN_KEY_SPLIT;
+    float *part_o = (float *)p, *part_ml = (float *)(p + ws_align(ASPLIT * rows * FD * 4));
     int rc = launch_gemm(AIm2Patch{images_chw, size, G}, w->patch_w, 3 * FPATCH * FPATCH, prow, FD, EpiPatch{w->patch_b, x, cells, T}, st);
     if (rc != SSLAM_OK) return rc;
     hipLaunchKernelGGL(prefix_rows_f32_kernel, dim3(n_frames * FPREFIX), dim3(64), 0, st, w->prefix, T, x);
@@ -804,8 +894,15 @@ extern "C" int sslam_vit_forward_f32(const float *images_chw, int n_frames, int 
         hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln1_g, ly.ln1_b, 1e-5f, rows, y);
         sslam_count_launches(1);
         if ((rc = launch_gemm_rows(y, FD, ly.wqkv, FD, rows, 3 * FD, TQKV{ly.bqkv, w->rope_cos, w->rope_sin, q, k, v, T}, st)) != SSLAM_OK) return rc;
-        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((nbh + 7) / 8 * 8 * subs)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs);
-        sslam_count_launches(1);
+        if (split) {
+            hipLaunchKernelGGL(attn_f32_kernel<true>, dim3((unsigned)(nbh * subs * ASPLIT)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs, part_o, part_ml);
+            hipLaunchKernelGGL(attn_f32_merge_kernel, dim3((unsigned)(((long long)nbh * T * 16 + 255) / 256)), dim3(256), 0, st, part_o, part_ml, y, T, nbh);
+            sslam_count_launches(2);
+        } else {
+            hipLaunchKernelGGL(attn_f32_kernel<false>, dim3((unsigned)((nbh + 7) / 8 * 8 * subs)), dim3(64 * AW), 0, st, q, k, v, y, T, nbh, subs,
+                               (float *)nullptr, (float *)nullptr);
+            sslam_count_launches(1);
+        }
         if ((rc = launch_gemm_rows(y, FD, ly.wo, FD, rows, FD, EpiResidual{ly.bo, ly.ls1, x}, st)) != SSLAM_OK) return rc;
         hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
         sslam_count_launches(1);

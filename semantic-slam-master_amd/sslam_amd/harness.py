@@ -344,13 +344,13 @@ def _push_vit_groups(pipe: SequencePipeline, seq: "StreamingSequence", feeder: "
     for a, b, img, ready in feeder:
         cur.wait_event(ready)
         if not grouped:
-            seq.push(pipe.tokens_from_images(img), img)
+            seq.push(pipe.tokens_from_images(img, batch_frames=n), img)
             continue
         if tok is None:
             tok = torch.empty((group, t_tok, lib.C_FEAT), dtype=torch.float32, device=pipe.device)
         if off == 0:
             g0 = a
-        pipe.tokens_from_images(img, out=tok[off:off + b - a])
+        pipe.tokens_from_images(img, out=tok[off:off + b - a], batch_frames=n)
         off += b - a
         if b == n or off + chunk > group:
             seq.push(tok[:off], feeder.dev[g0:b])
@@ -386,7 +386,7 @@ def run_frames(pipe: SequencePipeline, n: int, h: int, w: int, spacings=(1,), to
         # the pixels are first read by A9, the last stage of the extraction: A2..A7 run while the upload is in flight
         seq.push(tokens[a:b], img, images_ready=ready)
         if preprocess_too:
-            pipe.preprocess(img)
+            pipe.preprocess(img, reuse=True)
     return seq.result()
 
 

@@ -75,7 +75,7 @@ EXPORTS = [
     "sslam_workspace_bytes", "sslam_selector_saliency_workspace_bytes", "sslam_sim_argmax_workspace_bytes",
     "sslam_selector_saliency_ws", "sslam_sim_argmax_ws", "sslam_test_set_knob",
     "sslam_preprocess_u8_patches", "sslam_vit_forward_patches", "sslam_vit_f32_workspace_bytes", "sslam_vit_forward_f32",
-    "sslam_vit_f32_pack_linear_host",
+    "sslam_vit_f32_pack_linear_host", "sslam_vit_forward_f32_form",
 ]
 
 
@@ -130,6 +130,7 @@ def lib():
         L.sslam_vit_f32_workspace_bytes.restype = C.c_longlong
         L.sslam_vit_f32_workspace_bytes.argtypes = [i, i]
         L.sslam_vit_forward_f32.argtypes = [p, i, i, C.POINTER(VitWeightsF32), p, ll, p, p]
+        L.sslam_vit_forward_f32_form.argtypes = [p, i, i, C.POINTER(VitWeightsF32), p, ll, p, i, p]
         L.sslam_vit_f32_pack_linear_host.argtypes = [p, i, i, p]
         _lib = L
     return _lib
@@ -293,19 +294,22 @@ def preprocess_u8_patches(img, size, tab_h, tab_v, out=None):
     return out
 
 
-def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out=None, want_stats=True, bf16_copy=False):
-    """bf16_copy=True: returns (out, mean, var, out_bf16) - the bf16 copy is written by the same kernel pass."""
+def bn_tokens(tokens, n_prefix, group, gamma, beta, run_mean, run_var, train, eps, out=None, want_stats=True, bf16_copy=False,
+              out_bf16=None):
+    """bf16_copy=True: returns (out, mean, var, out_bf16) - the bf16 copy is written by the same kernel pass (into out_bf16 if given)."""
     n, t, c = tokens.shape
     assert c == C_FEAT and tokens.dtype == torch.float32
     cells = t - n_prefix
     if out is None:
         out = torch.empty((n, cells, c), dtype=torch.float32, device=tokens.device)
+    assert out.dtype == torch.float32 and out.numel() == n * cells * c and out.is_contiguous()
     mean = var = None
     if train and want_stats:
         mean = torch.empty((n // group, c), dtype=torch.float32, device=tokens.device)
         var = torch.empty_like(mean)
     if bf16_copy:
-        out_bf = torch.empty((n, cells, c), dtype=torch.bfloat16, device=tokens.device)
+        out_bf = out_bf16 if out_bf16 is not None else torch.empty((n, cells, c), dtype=torch.bfloat16, device=tokens.device)
+        assert out_bf.dtype == torch.bfloat16 and out_bf.numel() == n * cells * c and out_bf.is_contiguous()
         _run("bn_tokens_bf16copy", lib().sslam_bn_tokens_bf16copy, (tokens, gamma, beta, run_mean, run_var, out, out_bf, mean, var,),
          _dp(tokens), n, t, n_prefix, group, _dp(gamma), _dp(beta), _dp(run_mean),
                                               _dp(run_var), int(bool(train)), C.c_float(eps), _dp(out), _dp(out_bf), _dp(mean),
@@ -534,12 +538,21 @@ def vit_f32_workspace_bytes(n_frames: int, size: int) -> int:
     return b
 
 
-def vit_forward_f32(images_chw, weights: VitWeightsF32, workspace, out=None):
-    """(n, 3, S, S) fp32 -> tokens (n, 5 + (S/16)^2, 384) fp32 by the fp32-operand HIP ViT (reference numerics for A1)."""
+ATTN_ONE_PASS, ATTN_KEY_SPLIT, ATTN_KEY_SPLIT_MAX_FRAMES = 0, 1, 8          # include/sslam_hip.h
+
+
+def vit_forward_f32(images_chw, weights: VitWeightsF32, workspace, out=None, attention_form: int | None = None):
+    """(n, 3, S, S) fp32 -> tokens (n, 5 + (S/16)^2, 384) fp32 by the fp32-operand HIP ViT (reference numerics for A1).
+    attention_form: None - the library's choice by this launch's frame count (key split up to 8 frames); ATTN_ONE_PASS /
+    ATTN_KEY_SPLIT - the caller's (a batch cut into several launches passes the form of the whole batch to each)."""
     n, _, size, _ = images_chw.shape
     t = 5 + (size // 16) ** 2
     if out is None:
         out = torch.empty((n, t, C_FEAT), dtype=torch.float32, device=images_chw.device)
-    _run("vit_forward_f32", lib().sslam_vit_forward_f32, (images_chw, workspace, out,),
-         _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(), _dp(out))
+    if attention_form is None:
+        _run("vit_forward_f32", lib().sslam_vit_forward_f32, (images_chw, workspace, out,),
+             _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(), _dp(out))
+    else:
+        _run("vit_forward_f32_form", lambda *a: lib().sslam_vit_forward_f32_form(*a[:-1], int(attention_form), a[-1]), (images_chw, workspace, out,),
+             _dp(images_chw), n, size, C.byref(weights), _dp(workspace), workspace.numel() * workspace.element_size(), _dp(out))
     return out

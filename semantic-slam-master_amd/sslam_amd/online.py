@@ -52,6 +52,7 @@ class FrameStepper:
         self.n_frames = 0
         self._graph = None
         self._aux = None
+        self._held = None
 
     # the captured region: only launches on the current stream, static buffers on both sides
     def _body(self) -> None:
@@ -72,10 +73,29 @@ class FrameStepper:
                 self._body()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
+        # The graph bakes in the ADDRESSES of buffers the stepper does not own: the pipeline's scratch, the ViT's workspaces, the
+        # resampling and RoPE tables.  Their owners grow them by replacement (a later, larger pipe.run / tokens_from_images drops
+        # the old tensor), which would leave the graph reading and writing freed memory.  The stepper therefore keeps its own
+        # reference to every one of them from the warm-up on: a replaced buffer stays alive - and exclusively the graph's - for
+        # as long as the graph does.
+        self._held = self._external_buffers()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._body()
         self._graph = g
+
+    def _external_buffers(self) -> list:
+        p, held = self.pipe, []
+        held.append(p._ws)
+        held.extend(p._stage.values())
+        held.extend(p.tables._cache.values())
+        vh = p.vit_hip
+        if vh is not None:
+            held.extend(getattr(vh, "_side_ws", []) or [])
+            held.extend(getattr(vh, "_ws", []) or [])
+            held.extend(vh._rope.values())
+            held.append(vh._keep)
+        return held
 
     @torch.no_grad()
     def step(self, image_u8: torch.Tensor, tokens: torch.Tensor | None = None) -> dict:

@@ -47,6 +47,11 @@ class ExtractorConfig:
     def grid(self) -> int:
         return self.input_size // PATCH
 
+    def launch_group(self) -> int:
+        """Frames per launch group: chunk_frames, but never more than one 32-bit buffer descriptor can span (the saliency CNN
+        addresses the fp32 feature map through a single descriptor: < 4 GiB per launch; 2 965 frames at G = 40 are 7.3 GB)."""
+        return max(1, min(self.chunk_frames, (2 ** 32 - 1) // (self.grid ** 2 * 384 * 4)))
+
 
 def _np(v):
     return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
@@ -167,6 +172,8 @@ class SequencePipeline:
         lib.lib()   # fail loudly if the HIP library is not built
         if cfg.precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {cfg.precision!r}")
+        if vit_precision not in ("bf16", "fp32"):          # checked whether or not a ViT is given: a typo must not pass silently
+            raise ValueError(f"vit_precision must be 'bf16' or 'fp32', got {vit_precision!r}")
         self.bf16 = cfg.precision == "bf16"
         if selector_state is None or refiner_state is None:
             if empty_shapes is None:
@@ -177,6 +184,7 @@ class SequencePipeline:
             self.selector = PackedSelector(selector_state, self.device, self.bf16)
             self.refiner = PackedRefiner(refiner_state, self.device, self.bf16)
         self._ws = None             # caller-owned scratch handed to the *_ws entries (the library never allocates)
+        self._stage = {}            # pipeline-owned stage temporaries (features, their bf16 copy, the A0 image): see _stage_buffer
         c = lib.C_FEAT
         bn = bn_state or {}
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -196,13 +204,12 @@ class SequencePipeline:
                 if conv is None:
                     raise lib.SslamHipError(f"{type(vit).__name__} cannot run on the HIP ViT: {why}")
                 vit = conv
-            if vit_precision not in ("bf16", "fp32"):
-                raise ValueError(f"vit_precision must be 'bf16' or 'fp32', got {vit_precision!r}")
+            # the packers copy every tensor to the device themselves: the caller's module is NOT moved (nn.Module.to works in place)
             if vit_precision == "fp32":
                 from .vit_hip import HipViTF32
-                self.vit_hip = HipViTF32(vit.to(self.device), self.device)
+                self.vit_hip = HipViTF32(vit, self.device)
             else:
-                self.vit_hip = HipViT(vit.to(self.device), self.device)
+                self.vit_hip = HipViT(vit, self.device)
         self.vit_precision = vit_precision
 
     def weight_tensors(self) -> list:
@@ -217,16 +224,37 @@ class SequencePipeline:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    # ---------------------------------------------------------------------------------------------- stages
-    def preprocess(self, images_u8: torch.Tensor) -> torch.Tensor:
-        """A0: (N, H, W, 3) uint8 -> (N, 3, S, S) fp32, Pillow-exact (the ViT input)."""
-        n, h, w, _ = images_u8.shape
-        th, tv = self.tables.get(h, w, self.cfg.input_size, False)
-        return lib.preprocess_u8(images_u8, self.cfg.input_size, th, tv)
+    def _stage_buffer(self, name: str, shape: tuple, dtype) -> torch.Tensor:
+        """A pipeline-owned temporary of a stage, allocated once and reused by every launch group of every pass (grown by
+        replacement, never shrunk): the multi-GB intermediates - a launch group's fp32 features are 2.5 GB at G = 40 - do not
+        go back to the caching allocator between groups, whose state otherwise decided whether a pass ran at 52 k or 96 k
+        frames/s (bf16 mode, 2 965 frames).  Stages run in stream order on the caller's stream, so a buffer is free again by the
+        time the next group's producer writes it; results a CALLER keeps are never placed here (reuse=False paths allocate)."""
+        need = 1
+        for d in shape:
+            need *= int(d)
+        t = self._stage.get(name)
+        if t is None or t.numel() < need or t.dtype != dtype:
+            t = torch.empty(need, dtype=dtype, device=self.device)
+            self._stage[name] = t
+        return t[:need].view(shape)
 
-    def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    # ---------------------------------------------------------------------------------------------- stages
+    def preprocess(self, images_u8: torch.Tensor, reuse: bool = False) -> torch.Tensor:
+        """A0: (N, H, W, 3) uint8 -> (N, 3, S, S) fp32, Pillow-exact (the ViT input).
+        reuse: write into the pipeline's own A0 buffer (valid until the next reuse=True call) instead of a fresh tensor."""
+        n, h, w, _ = images_u8.shape
+        size = self.cfg.input_size
+        th, tv = self.tables.get(h, w, size, False)
+        out = self._stage_buffer("a0_image", (n, 3, size, size), torch.float32) if reuse else None
+        return lib.preprocess_u8(images_u8, size, th, tv, out=out)
+
+    def tokens_from_images(self, images_u8: torch.Tensor, vit_chunk: int | None = None, out: torch.Tensor | None = None,
+                           batch_frames: int | None = None) -> torch.Tensor:
         """A0 + A1: (N, H, W, 3) uint8 -> (N, 5 + G*G, 384) fp32 tokens via the HIP ViT, `vit_chunk` frames at a time.
-        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (82 frames at 448 x 448), alternating between two streams."""
+        Default chunk: HipViT.chunk_frames - whole rounds of the ViT's row-tile workgroups (82 frames at 448 x 448), alternating between two streams.
+        batch_frames: the length of the sequence these frames are a piece of, when the caller feeds it in pieces (the streaming
+        harness): the fp32 ViT picks its attention form by the batch, so that a frame's tokens do not depend on the cuts."""
         if self.vit_hip is None:
             raise lib.SslamHipError("this pipeline was built without a ViT: pass tokens, or construct it with vit=")
         if vit_chunk is None:
@@ -250,7 +278,8 @@ class SequencePipeline:
             if patches is not None:
                 self.vit_hip.forward_features(None, out=out[a:b], chunk=vit_chunk, patches=patches, size=size)
             else:
-                self.vit_hip.forward_features(self.preprocess(images_u8[a:b]), out=out[a:b], chunk=vit_chunk)
+                self.vit_hip.forward_features(self.preprocess(images_u8[a:b], reuse=self.vit_hip.n_streams < 2), out=out[a:b], chunk=vit_chunk,
+                                              batch_frames=max(n, batch_frames or 0))
         return out
 
     def preprocess_patches(self, images_u8: torch.Tensor):
@@ -259,21 +288,24 @@ class SequencePipeline:
         th, tv = self.tables.get(h, w, self.cfg.input_size, False)
         return lib.preprocess_u8_patches(images_u8, self.cfg.input_size, th, tv)
 
-    def features(self, tokens: torch.Tensor, bf16_copy: bool = False):
+    def features(self, tokens: torch.Tensor, bf16_copy: bool = False, reuse: bool = False):
         """A2: (N, 5 + G*G, 384) ViT tokens -> (N, G, G, 384) per-frame-normalised patch features
-        (bf16_copy: also their bf16 copy, written in the same pass, for the bf16-mode saliency CNN)."""
+        (bf16_copy: also their bf16 copy, written in the same pass, for the bf16-mode saliency CNN).
+        reuse: write into the pipeline's own feature buffers (valid until the next reuse=True call) - what extract() does."""
         g = self.cfg.grid
         if tokens.shape[1] != N_PREFIX + g * g:
             raise AssertionError(f"Expected {g * g} patches, got {tokens.shape[1] - N_PREFIX}")   # dino_backbone.py:94
+        flat = (tokens.shape[0], g * g, lib.C_FEAT)
+        o32 = self._stage_buffer("features", flat, torch.float32) if reuse else None
+        o16 = self._stage_buffer("features_bf16", flat, torch.bfloat16) if (reuse and bf16_copy) else None
         r = lib.bn_tokens(tokens, N_PREFIX, 1, self.bn_gamma, self.bn_beta, self.bn_mean, self.bn_var,
-                          self.cfg.bn_train_mode, self.cfg.bn_eps, want_stats=False, bf16_copy=bf16_copy)
+                          self.cfg.bn_train_mode, self.cfg.bn_eps, out=o32, want_stats=False, bf16_copy=bf16_copy, out_bf16=o16)
         shape = (tokens.shape[0], g, g, lib.C_FEAT)
         return (r[0].view(shape), r[3].view(shape)) if bf16_copy else r[0].view(shape)
 
     def launch_group(self) -> int:
-        """Frames per launch group: cfg.chunk_frames, but never more than one 32-bit buffer descriptor can span (the
-        saliency CNN addresses the fp32 feature map through a single descriptor: < 4 GiB per launch)."""
-        return max(1, min(self.cfg.chunk_frames, (2 ** 32 - 1) // (self.cfg.grid ** 2 * lib.C_FEAT * 4)))
+        """Frames per launch group (ExtractorConfig.launch_group: chunk_frames, capped by the 4 GiB a buffer descriptor spans)."""
+        return self.cfg.launch_group()
 
     def alloc_extract(self, n: int, with_intensity: bool) -> dict:
         """Output buffers of extract() for n frames (every launch group writes its slice: nothing is concatenated)."""
@@ -313,11 +345,11 @@ class SequencePipeline:
         cfg, s = self.cfg, self.selector
         ws = self.workspace(tokens.shape[0], 0)
         if self.bf16:
-            feat, feat_bf = self.features(tokens, bf16_copy=True)
+            feat, feat_bf = self.features(tokens, bf16_copy=True, reuse=True)
             lib.selector_saliency_bf16(feat_bf, s.w1p_bf16, s.b1, s.w2, s.b2, s.hidden, out=out["saliency"])
             del feat_bf
         else:
-            feat = self.features(tokens)
+            feat = self.features(tokens, reuse=True)
             lib.selector_saliency(feat, s.w1p, s.b1, s.w2, s.b2, s.hidden, out=out["saliency"], workspace=ws)
         lib.select_keypoints(out["saliency"], cfg.num_keypoints, cfg.nms_radius, cfg.min_score_percentile,
                              out=(out["keypoints_patch"], out["scores"], out["idx"], out["keypoints_pixel"], out["status"]))
@@ -380,7 +412,7 @@ class SequencePipeline:
         if with_preprocess and images_u8 is not None:
             step = self.launch_group()
             for a in range(0, images_u8.shape[0], step):
-                vit_in = self.preprocess(images_u8[a:a + step])      # A0: would feed the ViT (A1)
+                vit_in = self.preprocess(images_u8[a:a + step], reuse=True)      # A0: would feed the ViT (A1)
         out = dict(self.extract(tokens, images_u8))
         out.update(self.match(out["descriptors"], out["scores"], out.get("intensity")))
         if vit_in is not None:

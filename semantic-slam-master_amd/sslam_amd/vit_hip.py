@@ -175,10 +175,16 @@ class HipViTF32:
         also bounds the workspace (13.7 KB per token: 0.9 GB)."""
         return max(1, (512 * 128) // (5 + (size // 16) ** 2))
 
-    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None) -> torch.Tensor:
+    def forward_features(self, images: torch.Tensor, out: torch.Tensor | None = None, chunk: int | None = None,
+                         batch_frames: int | None = None) -> torch.Tensor:
         """(B, 3, S, S) fp32 cuda -> (B, 5 + (S/16)^2, 384) fp32 tokens (final-LayerNormed), launch groups of `chunk` frames one after
         the other on the caller's stream (n_streams = 2: alternating between two side streams as HipViT does - measured slower
-        here, see __init__); the caller's stream semantics are kept either way."""
+        here, see __init__); the caller's stream semantics are kept either way.
+        The attention's launch form follows the size of the BATCH, not of a launch group: up to 8 frames (the reference's own
+        callers: B = 1, B = 4) the key-split form (include/sslam_hip.h: 1.8 -> 1.33 ms for one frame), above it the one-pass
+        form for every group, a short last one included - so a frame's tokens do not depend on where a batch is cut.
+        batch_frames: the size of the batch these frames belong to when the caller itself hands it over in pieces
+        (SequencePipeline.tokens_from_images); default: this call's frame count."""
         n, _, s, s2 = images.shape
         assert s == s2 and s % 16 == 0 and images.is_cuda
         g = s // 16
@@ -197,6 +203,8 @@ class HipViTF32:
             out = torch.empty((n, 5 + g * g, lib.C_FEAT), dtype=torch.float32, device=images.device)
         starts = list(range(0, n, step))
         dev = images.device
+        # None: the library's own rule for a launch of <= 8 frames (key split; the test-only knob can switch it off)
+        form = None if (batch_frames or n) <= lib.ATTN_KEY_SPLIT_MAX_FRAMES else lib.ATTN_ONE_PASS
         for i in (0, 1) if len(starts) >= 2 and self.n_streams >= 2 else (0,):
             if self._ws[i] is None or self._ws[i].numel() < need:
                 self._ws[i] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -210,12 +218,12 @@ class HipViTF32:
                 if i < 2:
                     st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    lib.vit_forward_f32(x[a:a + step], self.w, self._ws[i & 1], out=out[a:a + step])
+                    lib.vit_forward_f32(x[a:a + step], self.w, self._ws[i & 1], out=out[a:a + step], attention_form=form)
             for st in self._side:
                 x.record_stream(st)
                 out.record_stream(st)
                 cur.wait_stream(st)
             return out
         for a in starts:
-            lib.vit_forward_f32(x[a:a + step], self.w, self._ws[0], out=out[a:a + step])
+            lib.vit_forward_f32(x[a:a + step], self.w, self._ws[0], out=out[a:a + step], attention_form=form)
         return out

@@ -369,6 +369,9 @@ def test_two_rank_rehearsal_on_one_gpu(T):
     assert par["ranks_checked"] == 2 and par["frames_checked_vs_oracle"] == 42
     assert par["boundaries"] == 1 and par["boundary_pairs_checked"] == 1 and par["boundary_matches_checked"] > 0
     assert par["pairs_checked"] == 41 and par["pairs_total"] == 41 and par["gathered_rows_equal_every_ranks_local_result"]
+    # the N > 1 legs a scaling run reports beside `value`: the per-rank host feed and the sharded step with the HIP ViT inside
+    assert d["with_upload"]["equal_to_resident_pass_on_every_rank"] and d["with_upload"]["value"] > 0
+    assert d["with_vit"]["pairs_gathered_on_rank0"] == 41 and d["with_vit"]["value"] > 0
     reh = d["rehearsal"]
     assert reh["sharded_equals_single_process"] and reh["pairs"] == 41 and reh["pairs_per_rank"] == [21, 20] and reh["matches"] > 0
 
@@ -524,3 +527,43 @@ def test_online_stepper_with_the_hip_vit(T, prec):
                 assert c == int(want["match_count"][i - 1]) and T.equal(o["matches"][:c], want["matches"][i - 1][:c])
     with pytest.raises(Exception, match="without a ViT"):
         FrameStepper(SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda"), 480, 640)
+
+
+@pytest.mark.parametrize("mode", ["tokens", "bf16", "fp32"])
+def test_online_stepper_graph_survives_the_pipeline_replacing_its_buffers(T, mode):
+    """A captured step bakes in the addresses of buffers the stepper does not own (the pipeline's scratch, the ViT's workspace), and
+    their owners grow them BY REPLACEMENT.  Capture at one frame, then push a 20-frame batch through the SAME pipeline (19 pairs: the
+    batched matcher's key scratch; 20 frames: a larger ViT workspace), fill whatever the allocator got back with junk, and keep
+    stepping: the replayed graph must still give the batched result (the stepper holds its own references from the capture on)."""
+    from sslam_amd.online import FrameStepper
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    from sslam_amd.vit import DinoV3ViT
+    T.manual_seed(5)
+    n = 20
+    imgs = T.from_numpy(synth.image_sequence(n)).cuda()
+    toks = T.from_numpy(synth.token_sequence(n, 28)).cuda() if mode == "tokens" else None
+    kw = {} if mode == "tokens" else dict(vit=DinoV3ViT().cuda().eval(), vit_precision=mode)
+    pv = SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cuda", **kw)
+    st = FrameStepper(pv, 480, 640, use_graph=True, tokens_in=(mode == "tokens"))
+    tk = (lambda i: toks[i]) if mode == "tokens" else (lambda i: None)
+    first = [{k: v.clone() for k, v in st.step(imgs[i], tk(i)).items() if v is not None} for i in range(2)]
+    ws_bytes = 0 if pv._ws is None else pv._ws.numel()            # (no reference kept here: the stepper's own must be what keeps it alive)
+    big = pv.run(imgs, tokens=toks) if mode == "tokens" else pv.run(imgs)
+    assert pv._ws.numel() > ws_bytes, "the batch was meant to outgrow the scratch"
+    del big
+    # the reference result: the first 8 frames as one batch (the ViTs' few-frame launch forms - two-launch MLP of the bf16 form,
+    # key-split attention of the fp32 form - cover 1..8 frames, so a one-frame step and this batch agree bit for bit)
+    want = pv.run(imgs[:8], tokens=toks[:8]) if mode == "tokens" else pv.run(imgs[:8])
+    T.cuda.synchronize()
+    junk = [T.full((sz,), 0xA5, dtype=T.uint8, device="cuda") for sz in (1 << 12, 1 << 16, 1 << 20, 1 << 22, 1 << 24, 1 << 26) for _ in range(3)]
+    T.cuda.synchronize()
+    for i in range(2):
+        for k in ("idx", "descriptors", "scores"):
+            assert T.equal(first[i][k], want[k][i]), (mode, k, i)
+    for i in range(2, 8):
+        o = st.step(imgs[i], tk(i))
+        for k in ("idx", "descriptors", "intensity", "scores"):
+            assert T.equal(o[k], want[k][i]), (mode, k, i)
+        c = int(o["match_count"])
+        assert c == int(want["match_count"][i - 1]) and T.equal(o["matches"][:c], want["matches"][i - 1][:c]), (mode, i)
+    assert all(int(j[0]) == 0xA5 and int(j[-1]) == 0xA5 for j in junk), "the replay wrote into memory it no longer owns"

@@ -382,3 +382,30 @@ def test_spacing_summary_is_the_reference_loop_over_its_pair_subset():
             else:
                 assert got["mean_quality"] is None and got["high_quality"] == 0
     assert spacing_summary(res, 20)["pairs"] == 0                     # a spacing the result does not hold
+
+
+def test_launch_groups_stay_below_one_buffer_descriptor():
+    """The saliency CNN addresses a launch's fp32 feature map through ONE 32-bit buffer descriptor: a launch group must stay below
+    4 GiB.  BASELINE configs[2] at its full length (2 965 frames at G = 40: 7.3 GB of features) is therefore cut into launch
+    groups by ExtractorConfig.launch_group(), which pipeline.extract, the sharded runner and bench.py's staged extraction all
+    iterate by (round 4 hit 'selector_saliency: unsupported shape' before they did)."""
+    import inspect
+
+    import bench
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    for name, (n, h, w, size, K) in bench.WORKLOADS.items():
+        cfg = ExtractorConfig(input_size=size, num_keypoints=K)
+        lg = cfg.launch_group()
+        assert 1 <= lg <= cfg.chunk_frames
+        assert lg * cfg.grid ** 2 * 384 * 4 < 2 ** 32, name
+    assert ExtractorConfig(input_size=640, num_keypoints=1024).launch_group() == 1024        # 1024 x 1600 x 1536 B = 2.5 GB
+    assert ExtractorConfig(input_size=960, num_keypoints=2048, chunk_frames=4096).launch_group() == 776   # capped: 776 x 3600 x 1536 B < 4 GiB
+    assert "launch_group()" in inspect.getsource(SequencePipeline.extract)
+    src = inspect.getsource(bench.main)
+    assert "step_ = pipe.launch_group()" in src and "range(0, t.shape[0], step_)" in src
+
+
+def test_pipeline_rejects_an_unknown_vit_precision_even_without_a_vit():
+    from sslam_amd.pipeline import ExtractorConfig, SequencePipeline
+    with pytest.raises(ValueError, match="vit_precision"):
+        SequencePipeline(ExtractorConfig(), synth.selector_state(0), synth.refiner_state(0), device="cpu", vit_precision="fp23")
