@@ -279,7 +279,8 @@ constexpr int HIMG_FLOATS = HIMG_ROWS * LDT;    // 36 864 B per buffer; two buff
 template <bool SMALL>
 __device__ __forceinline__ void halo_tile(float *hsmem, const float *__restrict__ feat, int n_rows, int G, const float *__restrict__ w1p,
                                           const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
-                                          float *__restrict__ sal, const int m0) {
+                                          float *__restrict__ sal, const int m0, const int m_end) {
+    // m_end: one past the last cell this tile computes (n_rows, or the end of the tile's frame in the per-frame tiling)
     constexpr int WN = SMALL ? 8 : 4, NI = SMALL ? 1 : 2, MI = SMALL ? 1 : 2, BM = 32 * MI * (8 / WN), HS = 256, NSLAB = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -326,7 +327,7 @@ __device__ __forceinline__ void halo_tile(float *hsmem, const float *__restrict_
     int a_base[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
-        const int m = min(m0 + wm * 32 * MI + mi * 32 + r, n_rows - 1);
+        const int m = min(m0 + wm * 32 * MI + mi * 32 + r, m_end - 1);
         a_base[mi] = (padded(m) - p_lo) * LDT + 4 * h;
     }
 
@@ -449,7 +450,7 @@ __device__ __forceinline__ void halo_tile(float *hsmem, const float *__restrict_
     __syncthreads();
     for (int t = tid; t < BM; t += 512) {
         const long long m = (long long)m0 + t;
-        if (m < n_rows) {
+        if (m < m_end) {
             float logit = b2[0];
 #pragma unroll
             for (int sb = 0; sb < NSLAB; sb++) logit = logit + red[sb * BM + t];
@@ -471,9 +472,36 @@ __global__ __launch_bounds__(512, 4) void selector_saliency_halo_kernel(const fl
     if (b < n_big) {
         const int q = n_big / 8, rem = n_big % 8, x = b % 8;
         const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
-        halo_tile<false>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, tile * 128);
+        halo_tile<false>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, tile * 128, n_rows);
     } else {
-        halo_tile<true>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, n_big * 128 + (b - n_big) * 32);
+        halo_tile<true>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, n_big * 128 + (b - n_big) * 32, n_rows);
+    }
+}
+
+// PER-FRAME TILING of the same form, for the grids whose frame-crossing tiles need more image rows than the LDS image has
+// (G = 40: 299, G = 60: 378 of 256): every frame is cut into its own tiles - tb = cells / 128 big ones, then 32-cell tiles for
+// the rest (G = 40: 12 + 2, nothing wasted; G = 60: 28 + 1 with 16 of its 32 cells beyond the frame, 0.4 %) - so no tile sees
+// a frame boundary and the image is the tile plus the halo (217 / 255 rows).  Same arithmetic and k order per cell: bit-identical
+// to the stage form it replaces there.  Grid: the big tiles up to the last whole round first (XCD-aware ranges), then every
+// remaining big tile as its four 32-cell quarters, then the frames' own small tiles.
+__global__ __launch_bounds__(512, 4) void selector_saliency_halo_frames_kernel(const float *__restrict__ feat, int n_rows, int G,
+                                                                                const float *__restrict__ w1p, const float *__restrict__ b1,
+                                                                                const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                                float *__restrict__ sal, int n_big, int n_quarter, int tb, int ts) {
+    extern __shared__ __attribute__((aligned(16))) float hsmem[];      // 2 x HIMG_FLOATS
+    const int b = blockIdx.x, cells = G * G;
+    if (b < n_big) {
+        const int q = n_big / 8, rem = n_big % 8, x = b % 8;
+        const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + b / 8;
+        const int f = tile / tb, j = tile - f * tb;
+        halo_tile<false>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, f * cells + j * 128, (f + 1) * cells);
+    } else if (b < n_big + n_quarter) {
+        const int u = b - n_big, tile = n_big + (u >> 2);
+        const int f = tile / tb, j = tile - f * tb;
+        halo_tile<true>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, f * cells + j * 128 + (u & 3) * 32, (f + 1) * cells);
+    } else {
+        const int u = b - n_big - n_quarter, f = u / ts, j = u - f * ts;
+        halo_tile<true>(hsmem, feat, n_rows, G, w1p, b1, w2, b2, sal, f * cells + tb * 128 + j * 32, (f + 1) * cells);
     }
 }
 
@@ -650,6 +678,27 @@ int halo_rows128(int G, long long n_rows) {
     return (int)worst;
 }
 
+// image rows the per-frame tiling needs: tiles start at multiples of 128 (big) or 32 (small) inside ONE frame
+int halo_rows_frame(int G) {
+    thread_local int c_G = 0, c_val = 0;
+    if (G == c_G) return c_val;
+    const int cells = G * G, G1 = G + 1;
+    auto padded = [&](int c) { const int y = c / G, x = c - y * G; return (y + 1) * G1 + x; };
+    int worst = 0;
+    const int tb = cells / 128;
+    for (int t = 0; t < tb; t++) {
+        const int need = padded(t * 128 + 127) - padded(t * 128) + 2 * (G + 2) + 1;
+        worst = need > worst ? need : worst;
+    }
+    for (int c0 = tb * 128; c0 < cells; c0 += 32) {
+        const int c1 = c0 + 31 < cells - 1 ? c0 + 31 : cells - 1;
+        const int need = padded(c1) - padded(c0) + 2 * (G + 2) + 1;
+        worst = need > worst ? need : worst;
+    }
+    c_G = G, c_val = worst;
+    return worst;
+}
+
 template <int WM, int WN, int NI, bool BD, int MI = 2>
 void launch(const float *feat, long long rows, int G, const float *w1p, const float *b1, const float *w2, const float *b2,
             float *sal, hipStream_t st) {
@@ -722,6 +771,15 @@ extern "C" int sslam_selector_saliency_ws(const float *feat, int n_frames, int G
         const int n_small = n_big < n_tiles ? (int)((rows - (long long)n_big * 128 + 31) / 32) : 0;
         hipLaunchKernelGGL(selector_saliency_halo_kernel, dim3(n_big + n_small), dim3(512), 2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G,
                            w1_packed, b1, w2, b2, sal, n_big);
+    } else if (hs == 256 && variant == 2 && !sslam_knob(KNOB_CONV_NO_HALO, 0) && G * G >= 128 && halo_rows_frame(G) <= HIMG_ROWS) {
+        // the grids whose frame-crossing tiles do not fit the image: every frame tiled on its own
+        const int cells = G * G, tb = cells / 128, ts = (cells - tb * 128 + 31) / 32;
+        const long long nb = (long long)n_frames * tb;
+        const int round = (int)sslam_knob(KNOB_CONV_TAIL, 512);
+        const long long n_big = round > 0 && nb > round ? nb / round * round : nb;
+        const long long n_quarter = (nb - n_big) * 4, n_small = (long long)n_frames * ts;
+        hipLaunchKernelGGL(selector_saliency_halo_frames_kernel, dim3((unsigned)(n_big + n_quarter + n_small)), dim3(512),
+                           2 * HIMG_FLOATS * sizeof(float), st, feat, (int)rows, G, w1_packed, b1, w2, b2, sal, (int)n_big, (int)n_quarter, tb, ts);
     } else if (hs == 256) {
         switch (variant) {
             case 0: launch<2, 4, 2, false>(feat, rows, G, w1_packed, b1, w2, b2, sal, st); break;

@@ -140,6 +140,18 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
     }
     __device__ __forceinline__ void load(bf16x8 (&a)[RT_KS], int row0, int kc, char *stg, const float *vec, int lane, int M) const {
         const int q = lane >> 3, p = lane & 7, r = lane & 31, h = lane >> 5;
+        // The transposition tile of THIS prologue: rows of exactly 128 B, the 16-byte chunk c of row r at chunk c ^ tau(r),
+        // tau = (r1, r3, r4 ^ r0) (bits of r, low to high).  Writes are row-major 8-byte units - a ds_write_b64 group is 16
+        // contiguous lanes = 2 rows x 8 units of one 64-byte half: tau's top bit differs between rows r and r + 1, so the two
+        // rows take opposite halves of the 128-byte bank window (with the 144-byte rows of the other users they overlapped:
+        // 2-way on every store).  Reads are the fragment side - lane (r, h) takes chunk 2 j + h of row r - and in each 16-lane
+        // group of a ds_read_b128 the eight even rows have eight different (r1, r3, r4), the odd rows likewise, and even / odd rows
+        // sit in opposite halves of the 256-byte bank row: conflict-free both ways.
+        const int tq = ((q >> 1) & 1) | ((q & 1) << 2);                                   // tau of row 8 i + q, up to the i bits
+        const int tr = ((r >> 1) & 1) | (((r >> 3) & 1) << 1) | ((((r >> 4) ^ r) & 1) << 2);
+        char *wbase = stg + q * 128 + 8 * p;
+        const char *rbase = stg + r * 128;
+        const int hr = h ^ tr;
         float mean[4], rstd[4], nmr[4];
         const float *xr[4];
         f32x4 st4[4];
@@ -182,11 +194,13 @@ struct ProLN {            // A = LayerNorm(x) of the fp32 residual stream, stati
                               __builtin_fmaf(__builtin_fmaf(v.y, rstd[i], nmr[i]), gm.y, bt.y));                      \
             o.y = pack_bf16x2(__builtin_fmaf(__builtin_fmaf(v.z, rstd[i], nmr[i]), gm.z, bt.z),                       \
                               __builtin_fmaf(__builtin_fmaf(v.w, rstd[i], nmr[i]), gm.w, bt.w));                      \
-            *reinterpret_cast<uint2 *>(stg + (8 * i + q) * RT_STG_ROW + 64 * hf + 8 * p) = o;                         \
+            /* unit 8 hf + p of row 8 i + q, chunk index xor tau: only bits 1..3 of the unit move, p's low bit stays */      \
+            const int ti = tq ^ ((i & 1) << 1) ^ (((i >> 1) & 1) << 2);                                               \
+            *reinterpret_cast<uint2 *>(wbase + 8 * i * 128 + (((8 * hf + (p & 6)) ^ (2 * ti)) - (p & 6)) * 8) = o;    \
         }                                                                                                             \
     }                                                                                                                 \
     _Pragma("unroll") for (int j = 0; j < 4; j++)                                                                     \
-        a[4 * (c_) + j] = *reinterpret_cast<const bf16x8 *>(stg + r * RT_STG_ROW + 32 * j + 16 * h);
+        a[4 * (c_) + j] = *reinterpret_cast<const bf16x8 *>(rbase + 16 * ((2 * j) ^ hr));
         LN_WAIT(xq[0], 40)             // batch c has landed once at most 8 (5 - c) younger loads are outstanding
         LN_EMIT(xq[0], 0)
         LN_WAIT(xq[1], 32)
@@ -435,12 +449,23 @@ __device__ __forceinline__ float gelu_poly(float v) {
 
 // rows of 64 bf16 (two slices = 128 B per token) leave the staging tile as full lines: dst(i) = address of the 128-byte
 // row segment of token row0 + 8 i + q
+//
+// The bf16 pair tile (32 tokens x 128 B) is SWIZZLED at 8-byte granularity, rows of exactly 128 B: unit u (0..15) of row r sits at
+// r * 128 + 8 * (u ^ sw(r)), sw(r) = 2 (r & 7) + ((r >> 3) & 1).  Writes come from the transposed side - lane (r, h) stores unit
+// 2 g + h: a ds_write_b64 is served in groups of 16 CONTIGUOUS lanes (r .. r + 15, one h) against 32 banks, and with any padded
+// row stride that keeps rows 16-byte aligned the lanes r and r + 8 meet on one bank (the 144-byte rows of the other epilogues:
+// 2-way on every store, a quarter of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); sw sends the 16 lanes to 16 different
+// units.  Reads are row-major 16-byte pieces - lane (q, p) takes chunk p of row 8 i + q, found at chunk p ^ q, its two 8-byte
+// halves exchanged in the rows with (r >> 3) & 1 = i & 1 = 1 (known at compile time: free) - and the four 16-lane groups of a
+// ds_read_b128 land on 16 different 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int rt_pair_sw(int r) { return 2 * (r & 7) + ((r >> 3) & 1); }
 template <class RowPtr>
 __device__ __forceinline__ void rt_store_pair(const char *stg, int row0, int lane, int M, RowPtr dst) {
     const int q = lane >> 3, p = lane & 7;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + (8 * i + q) * RT_STG_ROW + 16 * p);
+        u32x4 v = *reinterpret_cast<const u32x4 *>(stg + (8 * i + q) * 128 + 16 * (p ^ q));
+        if (i & 1) v = u32x4{v[2], v[3], v[0], v[1]};
         if (row0 + 8 * i + q < M) *reinterpret_cast<u32x4 *>(dst(i) + 8 * p) = v;
     }
 }
@@ -457,6 +482,8 @@ struct EpiGelu {
     __device__ __forceinline__ void prefetch(State &, int, int, int, int) const {}
     __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &, int row0, int nt, char *stg, const float *, int lane, int M) const {
         const int q = lane >> 3, r = lane & 31, h = lane >> 5;
+        char *wrow = stg + r * 128;
+        const int sw = rt_pair_sw(r);
 #pragma unroll
         for (int pp = 0; pp < 3; pp++) {
 #pragma unroll
@@ -467,7 +494,7 @@ struct EpiGelu {
                     uint2 o;
                     o.x = pack_bf16x2(gelu_poly(acc[s][4 * g + 0]), gelu_poly(acc[s][4 * g + 1]));
                     o.y = pack_bf16x2(gelu_poly(acc[s][4 * g + 2]), gelu_poly(acc[s][4 * g + 3]));
-                    *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 64 * s2 + 16 * g + 8 * h) = o;
+                    *reinterpret_cast<uint2 *>(wrow + 8 * ((8 * s2 + 2 * g + h) ^ sw)) = o;
                 }
             rt_store_pair(stg, row0, lane, M, [&](int i) { return out + (long long)(row0 + 8 * i + q) * ldo + RT_NT * nt + 64 * pp; });
         }
@@ -531,16 +558,22 @@ struct EpiQKV {
     const float *cosb, *sinb;
     bf16 *q, *k, *v;
     int T, G;
-    int extra_floats() const { return 4 * 16 * G; }
+    // rows of the x tables are ROPE_RS = 20 floats apart (16 used): the 16 lanes of a ds_read_b128 group hold tokens of up to 16
+    // different patch columns, and with rows of 64 B the columns px and px + 4 share their four banks (4-way on every x-table
+    // read); 80-byte rows put 16 consecutive columns on 16 different 16-byte slots of the 256-byte bank row.  The y tables keep
+    // 64-byte rows (a group sees one or two patch rows) - at G = 28 the kernel's LDS then stays below half a CU's 160 KB.
+    static constexpr int ROPE_RS = 20;
+    int extra_floats() const { return 2 * 16 * G + 2 * ROPE_RS * G; }
     __device__ __forceinline__ void fill_extra(float *rope, int tid) const {
-        // [cos_y | sin_y | cos_x | sin_x], each (G, 16): row py of the y tables from token (py, 0), row px of the x tables
-        // from token (0, px)
+        // [cos_y | sin_y] each (G, 16), then [cos_x | sin_x] each (G, ROPE_RS): row py of the y tables from token (py, 0), row px
+        // of the x tables from token (0, px)
+        float *rx = rope + 32 * G;
         for (int i = tid; i < 16 * G; i += 256) {
-            const int p = i >> 4, dd = i & 15;
+            const int p = i >> 4, dd = i & 15, j = p * ROPE_RS + dd;
             rope[i] = cosb[(long long)p * G * VHD + dd];
             rope[16 * G + i] = sinb[(long long)p * G * VHD + dd];
-            rope[32 * G + i] = cosb[(long long)p * VHD + 16 + dd];
-            rope[48 * G + i] = sinb[(long long)p * VHD + 16 + dd];
+            rx[j] = cosb[(long long)p * VHD + 16 + dd];
+            rx[ROPE_RS * G + j] = sinb[(long long)p * VHD + 16 + dd];
         }
     }
     struct State {};
@@ -548,6 +581,8 @@ struct EpiQKV {
     __device__ __forceinline__ void prefetch(State &, int, int, int, int) const {}
     __device__ __forceinline__ void tile(f32x16 (&acc)[RT_SL], State &, int row0, int nt, char *stg, const float *rope, int lane, int M) const {
         const int q8 = lane >> 3, r = lane & 31, h = lane >> 5;
+        char *wrow = stg + r * 128;
+        const int sw = rt_pair_sw(r);
         const int which = nt >> 1;
         bf16 *dst = which == 0 ? q : (which == 1 ? k : v);
         // rotation coefficients of this lane's token: v tiles, [CLS] and register tokens use the identity (cos 1, sin 0)
@@ -565,8 +600,8 @@ struct EpiQKV {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 // the accumulators are only READ (rotating them in place made hipcc keep two copies and spill the A fragments)
-                const float *tc = rope + (g < 2 ? 0 : 32 * G) + (g < 2 ? py : px) * 16 + 8 * (g & 1) + 4 * h;
-                const float4 cs = *reinterpret_cast<const float4 *>(tc), sn = *reinterpret_cast<const float4 *>(tc + 16 * G);
+                const float *tc = (g < 2 ? rope + py * 16 : rope + 32 * G + px * ROPE_RS) + 8 * (g & 1) + 4 * h;
+                const float4 cs = *reinterpret_cast<const float4 *>(tc), sn = *reinterpret_cast<const float4 *>(tc + (g < 2 ? 16 : ROPE_RS) * G);
                 const float cv[4] = {cs.x * rot + keep, cs.y * rot + keep, cs.z * rot + keep, cs.w * rot + keep};
                 const float sv[4] = {sn.x * rot, sn.y * rot, sn.z * rot, sn.w * rot};
                 float o0[4], o1[4];
@@ -576,8 +611,8 @@ struct EpiQKV {
                     o0[i] = x0 * cv[i] - x1 * sv[i];
                     o1[i] = x1 * cv[i] + x0 * sv[i];
                 }
-                *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 16 * g + 8 * h) = make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3]));
-                *reinterpret_cast<uint2 *>(stg + r * RT_STG_ROW + 64 + 16 * g + 8 * h) = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
+                *reinterpret_cast<uint2 *>(wrow + 8 * ((2 * g + h) ^ sw)) = make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3]));
+                *reinterpret_cast<uint2 *>(wrow + 8 * ((8 + 2 * g + h) ^ sw)) = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
             }
             const int head = 3 * (nt & 1) + pp;
             rt_store_pair(stg, row0, lane, M, [&](int i) { return dst + orow[i] + (long long)head * T * VHD; });
@@ -894,25 +929,29 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const bf16 *__restrict__ q
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) qf[ks] = *reinterpret_cast<const bf16x8 *>(q + (bh + qi) * VHD + ks * 16 + 8 * h);
 
-    // staging: thread (row = tid >> 2, c4 = tid & 3) moves the 16-byte pieces c4 and c4 + 4 of key row `row` of K and V
-    const int srow = tid >> 2, c4 = tid & 3;
-    const int vswz = 4 * ((srow >> 1) & 1);
+    // staging: thread (row = tid >> 3, c8 = tid & 7) moves the 16-byte piece c8 of key rows `row` and `row + 32` of K and V.  A
+    // ds_write_b128 is served in groups of 8 CONTIGUOUS lanes against 32 banks: here a group stores the 8 pieces of ONE row - 128
+    // contiguous bytes, every bank once (four lanes on each of two rows, as before: the rows' 144- / 128-byte strides put them on
+    // the same banks - 2-way on every store, a quarter of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT)
+    const int srow = tid >> 3, c8 = tid & 7;
+    const int vswz = 4 * ((srow >> 1) & 1);                  // = that of row srow + 32
     u32x4 rk[2], rv[2];
 #define A_LOAD(kt)                                                                                   \
     {                                                                                                \
         /* keys beyond T re-read row T - 1 (finite data): their scores are set to -inf below, so P = 0 */   \
-        const long long off = (bh + min((kt) * AKT + srow, T - 1)) * VHD + c4 * 8;                   \
-        rk[0] = *reinterpret_cast<const u32x4 *>(k + off);                                           \
-        rk[1] = *reinterpret_cast<const u32x4 *>(k + off + 32);                                      \
-        rv[0] = *reinterpret_cast<const u32x4 *>(v + off);                                           \
-        rv[1] = *reinterpret_cast<const u32x4 *>(v + off + 32);                                      \
+        const long long off0 = (bh + min((kt) * AKT + srow, T - 1)) * VHD + c8 * 8;                  \
+        const long long off1 = (bh + min((kt) * AKT + 32 + srow, T - 1)) * VHD + c8 * 8;             \
+        rk[0] = *reinterpret_cast<const u32x4 *>(k + off0);                                          \
+        rk[1] = *reinterpret_cast<const u32x4 *>(k + off1);                                          \
+        rv[0] = *reinterpret_cast<const u32x4 *>(v + off0);                                          \
+        rv[1] = *reinterpret_cast<const u32x4 *>(v + off1);                                          \
     }
 #define A_STORE(buf)                                                                                 \
     {                                                                                                \
-        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + srow * KLD + c4 * 8) = rk[0];            \
-        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + srow * KLD + c4 * 8 + 32) = rk[1];       \
-        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + srow * 128 + ((c4 ^ vswz) << 4)) = rv[0];        \
-        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + srow * 128 + (((c4 + 4) ^ vswz) << 4)) = rv[1];  \
+        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + srow * KLD + c8 * 8) = rk[0];            \
+        *reinterpret_cast<u32x4 *>(Ks + (buf) * AKT * KLD + (32 + srow) * KLD + c8 * 8) = rk[1];     \
+        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + srow * 128 + ((c8 ^ vswz) << 4)) = rv[0];        \
+        *reinterpret_cast<u32x4 *>(Vs + (buf) * AKT * 128 + (32 + srow) * 128 + ((c8 ^ vswz) << 4)) = rv[1]; \
     }
     // transposing V reads: lane (group G = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3) addresses key row (.. + q4),
     // d = 32 dt + 16 (G & 1) + 4 p4; it receives d = 32 dt + (lane & 31), keys (.. + 0..3)

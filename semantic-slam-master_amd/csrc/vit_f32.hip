@@ -412,6 +412,90 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
 #endif
 }
 
+// FEW-FRAME FORM of a residual GEMM with a long K (the down projection, K = 1536; part of the form a batch of <= 8 frames runs,
+// include/sslam_hip.h SSLAM_ATTN_KEY_SPLIT).  One frame is 25 row tiles of 32: in the one-tile-wave form above that is 75 workgroups
+// whose every wave walks 768 dependent MFMAs (21 us of matrix time on 75 of 256 CUs), and at four frames 312 workgroups on 256
+// CUs - the CUs that got two take twice as long.  Here a workgroup is 32 rows x 64 columns and its four waves are (column tile,
+// K HALF): waves 0 / 1 sum k < K / 2, waves 2 / 3 the rest, and the halves meet in LDS as (first half) + (second half) - a fixed
+// order, so the result is deterministic and independent of the batch; against the single chain it differs in the last bits,
+// like the key-split attention, and is used under the same rule.  Twice the workgroups, half the chain: one frame 33 -> 17 us.
+template <class Epi>
+__global__ __launch_bounds__(256, 3) void gemm_f32_rows_ks2_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
+                                                                    long long M, int ntn64, Epi epi) {
+    static_assert(!Epi::TRANSPOSED, "residual epilogue only");
+    __shared__ float part[2][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, kh = wave >> 1;
+    const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const long long m0 = (long long)(bx + 8 * (bj / ntn64)) * 32;
+    if (m0 >= M) return;                                             // the whole workgroup
+    const int n0 = (bj % ntn64) * 64 + wn * 32;
+    const int groups = K / 8, g0 = kh * (groups / 2), g1 = g0 + groups / 2;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0xfffffffe, 0x00020000);
+    long long ra = m0 + r;
+    if (ra > M - 1) ra = M - 1;
+    const unsigned ao0 = (unsigned)(ra * lda * 4 + 16 * h);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, 0x7fffffff, 0x00020000);
+    const int wo0 = (n0 / 32) * groups * 1024, loff = lane * 16;
+    struct Frag {
+        f32x4 a, b;
+    };
+    Frag q0, q1, q2, q3;
+    auto load = [&](Frag &d, int G) {
+        d.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao0, G * 32, 0));
+        d.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo0 + G * 1024, 0));
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][1][e] = acc[1][0][e] = acc[1][1][e] = 0.0f;
+    load(q0, g0);
+    load(q1, g0 + 1);
+    load(q2, g0 + 2);
+    auto mma = [&](const Frag &c) {
+#pragma unroll
+        for (int st = 0; st < 4; st++) acc[0][0] = mfma32(c.a[st], c.b[st], acc[0][0]);
+    };
+#pragma unroll 1
+    for (int G = g0; G < g1; G += 4) {
+        load(q3, min(G + 3, g1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(q0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(q0, min(G + 4, g1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(q1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(q1, min(G + 5, g1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(q2);
+        __builtin_amdgcn_sched_barrier(0);
+        load(q2, min(G + 6, g1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(q3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) part[wn][e * 64 + lane] = acc[0][0][e];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][0][e] + part[wn][e * 64 + lane];
+    epi.template operator()<1, 1>(acc, m0, n0, r, h, M);
+}
+
+template <class Epi>
+int launch_gemm_rows_ks2(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
+    if (K % 64 || N % 64) return SSLAM_E_UNSUPPORTED;              // two halves of whole 4-group rounds
+    const int ntn64 = N / 64;
+    const long long blocks = ((M + 31) / 32 + 7) / 8 * 8 * ntn64;
+    hipLaunchKernelGGL((gemm_f32_rows_ks2_kernel<Epi>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn64, epi);
+    sslam_count_launches(1);
+    return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
+}
+
 #ifdef SSLAM_CLOCK_PROBE
 extern "C" int sslam_probe_gemm_f32_select(int K, int ntn) {
     const int v[2] = {K, ntn};
@@ -907,7 +991,9 @@ extern "C" int sslam_vit_forward_f32_form(const float *images_chw, int n_frames,
         hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
         sslam_count_launches(1);
         if ((rc = launch_gemm_rows(y, FD, ly.wup, FD, rows, FMLP, TGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
-        if ((rc = launch_gemm_rows(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
+        if (split) {       // few-frame form: the long-K residual GEMM in two K halves per workgroup
+            if ((rc = launch_gemm_rows_ks2(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
+        } else if ((rc = launch_gemm_rows(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
     }
     hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);
     SSLAM_CHECK_LAUNCH();
