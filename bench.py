@@ -24,6 +24,10 @@ for p in (ROOT, os.path.join(ROOT, "semantic-slam-master_amd"), os.path.join(ROO
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# dmabuf IPC: RCCL / device-buffer sharing between the rank processes of one node fails on this driver with the legacy IPC mode
+# (hipIpcGetMemHandle: invalid argument); must be in the environment before the HIP runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -294,8 +294,8 @@ int sslam_vit_forward_f32(const float *images_chw, int n_frames, int size, const
  *                            launch: deterministic, independent of the batch, ~1e-6 relative from the one-pass form (another
  *                            summation order of the same softmax); n_frames <= SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES, else
  *                            SSLAM_E_INVALID (the workspace holds the partials only up to that size).  The same form runs the
- *                            down projection (K = 1536) with each workgroup's waves summing one K half each, the halves added
- *                            in a fixed order: the few-frame form of the forward as a whole.
+ *                            down projection (K = 1536) with the four waves of a workgroup summing one K quarter each, the
+ *                            quarters added in a fixed order: the few-frame form of the forward as a whole.
  * sslam_vit_forward_f32 is this entry with form = KEY_SPLIT when n_frames <= SSLAM_ATTN_KEY_SPLIT_MAX_FRAMES, else ONE_PASS; a
  * caller that cuts one batch into several launches passes the form of the WHOLE batch to each, so that a frame's tokens do not
  * depend on where the cuts fall (sslam_amd/vit_hip.py does). */

@@ -415,23 +415,24 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_kernel(const float *__re
 // FEW-FRAME FORM of a residual GEMM with a long K (the down projection, K = 1536; part of the form a batch of <= 8 frames runs,
 // include/sslam_hip.h SSLAM_ATTN_KEY_SPLIT).  One frame is 25 row tiles of 32: in the one-tile-wave form above that is 75 workgroups
 // whose every wave walks 768 dependent MFMAs (21 us of matrix time on 75 of 256 CUs), and at four frames 312 workgroups on 256
-// CUs - the CUs that got two take twice as long.  Here a workgroup is 32 rows x 64 columns and its four waves are (column tile,
-// K HALF): waves 0 / 1 sum k < K / 2, waves 2 / 3 the rest, and the halves meet in LDS as (first half) + (second half) - a fixed
-// order, so the result is deterministic and independent of the batch; against the single chain it differs in the last bits,
-// like the key-split attention, and is used under the same rule.  Twice the workgroups, half the chain: one frame 33 -> 17 us.
+// CUs - the CUs that got two take twice as long.  Here a workgroup is ONE 32 x 32 output tile and its four waves are the four K
+// QUARTERS: wave q sums k in [q K / 4, (q + 1) K / 4) as one fma chain, the quarters meet in LDS and wave 0 adds them in the
+// fixed order ((q0 + q1) + q2) + q3 - deterministic and independent of the batch; against the single chain the result differs in
+// the last bits, like the key-split attention, and the form is used under the same rule.  Four times the workgroups, a quarter
+// of the chain each: the launch fills the chip at one frame (300 workgroups) and balances at four (1 188 quarter-length units on
+// 768 slots instead of 312 full-length ones on 256 CUs).
 template <class Epi>
-__global__ __launch_bounds__(256, 3) void gemm_f32_rows_ks2_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
-                                                                    long long M, int ntn64, Epi epi) {
+__global__ __launch_bounds__(256, 3) void gemm_f32_rows_ks4_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Wp, int K,
+                                                                    long long M, int ntn32, Epi epi) {
     static_assert(!Epi::TRANSPOSED, "residual epilogue only");
-    __shared__ float part[2][16 * 64];
+    __shared__ float part[3][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, kh = wave >> 1;
+    const int kq = __builtin_amdgcn_readfirstlane(tid >> 6);         // this wave's K quarter
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
-    const long long m0 = (long long)(bx + 8 * (bj / ntn64)) * 32;
+    const long long m0 = (long long)(bx + 8 * (bj / ntn32)) * 32;
     if (m0 >= M) return;                                             // the whole workgroup
-    const int n0 = (bj % ntn64) * 64 + wn * 32;
-    const int groups = K / 8, g0 = kh * (groups / 2), g1 = g0 + groups / 2;
+    const int n0 = (bj % ntn32) * 32;
+    const int groups = K / 8, g0 = kq * (groups / 4), g1 = g0 + groups / 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0xfffffffe, 0x00020000);
     long long ra = m0 + r;
     if (ra > M - 1) ra = M - 1;
@@ -475,23 +476,23 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_rows_ks2_kernel(const float *
         mma(q3);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (kh == 1) {
+    if (kq > 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) part[wn][e * 64 + lane] = acc[0][0][e];
+        for (int e = 0; e < 16; e++) part[kq - 1][e * 64 + lane] = acc[0][0][e];
     }
     __syncthreads();
-    if (kh == 1) return;
+    if (kq > 0) return;
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[0][0][e] = acc[0][0][e] + part[wn][e * 64 + lane];
+    for (int e = 0; e < 16; e++) acc[0][0][e] = ((acc[0][0][e] + part[0][e * 64 + lane]) + part[1][e * 64 + lane]) + part[2][e * 64 + lane];
     epi.template operator()<1, 1>(acc, m0, n0, r, h, M);
 }
 
 template <class Epi>
-int launch_gemm_rows_ks2(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
-    if (K % 64 || N % 64) return SSLAM_E_UNSUPPORTED;              // two halves of whole 4-group rounds
-    const int ntn64 = N / 64;
-    const long long blocks = ((M + 31) / 32 + 7) / 8 * 8 * ntn64;
-    hipLaunchKernelGGL((gemm_f32_rows_ks2_kernel<Epi>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn64, epi);
+int launch_gemm_rows_ks4(const float *A, int lda, const float *Wp, int K, long long M, int N, Epi epi, hipStream_t st) {
+    if (K % 128 || N % 32) return SSLAM_E_UNSUPPORTED;             // four quarters of whole 4-group rounds
+    const int ntn32 = N / 32;
+    const long long blocks = ((M + 31) / 32 + 7) / 8 * 8 * ntn32;
+    hipLaunchKernelGGL((gemm_f32_rows_ks4_kernel<Epi>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, Wp, K, M, ntn32, epi);
     sslam_count_launches(1);
     return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
 }
@@ -618,8 +619,16 @@ __global__ __launch_bounds__(64 * AW, 3) void attn_f32_kernel(const float *__res
     int bh, sub, split = 0;
     if constexpr (SPLIT) {
         // a few hundred workgroups at most: the hardware deals them round-robin over the XCDs and their CUs, one per CU
-        const int b = blockIdx.x;
-        split = b % ASPLIT, sub = (b / ASPLIT) % subs, bh = b / (ASPLIT * subs);
+        // the workgroups of a (frame, head)'s last query tile group with idle waves (T = 789: 25 tiles = 6 x 4 + 1) are dealt after all
+        // full ones, as in the one-pass form: four frames are 720 full workgroups - one round of the 768 slots - and 120 light ones
+        const int n_qt_ = (T + 31) / 32, heavy = (n_qt_ % AW) ? subs - 1 : subs;
+        int b = blockIdx.x;
+        if (b < nbh * heavy * ASPLIT) {
+            split = b % ASPLIT, sub = (b / ASPLIT) % heavy, bh = b / (ASPLIT * heavy);
+        } else {
+            b -= nbh * heavy * ASPLIT;
+            split = b % ASPLIT, sub = heavy, bh = b / ASPLIT;
+        }
     } else {
         const int n_qt_ = (T + 31) / 32, heavy = (n_qt_ % AW) ? subs - 1 : subs, n_chunks = (nbh + 7) / 8;
         int b = blockIdx.x, chunk;
@@ -991,8 +1000,8 @@ extern "C" int sslam_vit_forward_f32_form(const float *images_chw, int n_frames,
         hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, ly.ln2_g, ly.ln2_b, 1e-5f, rows, y);
         sslam_count_launches(1);
         if ((rc = launch_gemm_rows(y, FD, ly.wup, FD, rows, FMLP, TGelu{ly.bup, hid}, st)) != SSLAM_OK) return rc;
-        if (split) {       // few-frame form: the long-K residual GEMM in two K halves per workgroup
-            if ((rc = launch_gemm_rows_ks2(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
+        if (split) {       // few-frame form: the long-K residual GEMM in four K quarters per workgroup
+            if ((rc = launch_gemm_rows_ks4(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
         } else if ((rc = launch_gemm_rows(hid, FMLP, ly.wdown, FMLP, rows, FD, EpiResidual{ly.bdown, ly.ls2, x}, st)) != SSLAM_OK) return rc;
     }
     hipLaunchKernelGGL(ln_rows_f32_kernel, dim3(ln_grid), dim3(256), 0, st, x, w->norm_g, w->norm_b, 1e-5f, rows, tokens_out);

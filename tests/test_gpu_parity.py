@@ -101,11 +101,15 @@ def _packed_selector(T, hip, sd):
 
 
 @pytest.mark.parametrize("form", ["latency2", "latency", "throughput", "throughput_tail", "throughput_stage"])
-@pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (60, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256)])
+@pytest.mark.parametrize("grid,frames,hidden", [(28, 3, 256), (40, 1, 256), (60, 1, 256), (28, 2, 128), (5, 2, 256), (14, 5, 256),
+                                                (40, 3, 256), (60, 2, 256), (44, 3, 256)])
 def test_selector_saliency(T, hip, grid, frames, hidden, form, knob):
     """Every launch shape of the conv, all bit-identical: 32-cell tiles split over two workgroups on the halo image (few
     frames), 32-row workgroups of 8 waves, 128-row workgroups on the halo image (G = 28), the same with the last partial round cut into 32-cell tiles, and the
-    stage-per-tap form."""
+    stage-per-tap form.  At G = 40 / 44 / 60 the throughput forms run the PER-FRAME tiling of the halo form (a tile that crosses a
+    frame boundary there needs more image rows than the LDS image has): several frames, frame ends inside 32-cell tiles (G = 60:
+    16 of 32 cells; G = 44: 16), and with rounds of 4 big tiles a big tile cut into its four quarters (G = 44, 3 frames: 45 big
+    tiles = 11 rounds + 1)."""
     knob("SSLAM_CONV_LATENCY_ROWS", "0" if form.startswith("throughput") else str(1 << 30))
     knob("SSLAM_CONV_LAT2_ROWS", str(1 << 30) if form == "latency2" else "0")
     if form == "throughput_stage":
