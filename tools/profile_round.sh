@@ -5,7 +5,7 @@
 # Writes gpurun_out/<tag>_*: copy the ones to be judged into profiles/ afterwards.  Raw traces stay in /tmp on the box.
 # rocprofv3 is always given the program itself after `--`; --pmc passes carry only --kernel-trace (no other trace domain).
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-abc}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
