@@ -754,6 +754,10 @@ def main():
     # (what arrived is what was computed).  Any mismatch on any rank: no value.
     from oracle import ora
     from oracle_check import blocks_for, check_pass, compare_block, oracle_block
+    if rank == 0:
+        ora.lib()                 # (re)builds oracle/_build/liboracle.so if its sources are newer: one rank only, the others load it after
+    if world > 1:
+        dist.barrier()
     ora.set_num_threads(max(1, ora.host_threads() // world))
     want = args.parity_frames if args.parity_frames >= 0 else (n if grid <= 28 and n <= 1400 else 258)
     tpar = time.perf_counter()
