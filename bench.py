@@ -753,7 +753,7 @@ def main():
     # and compares a digest of every rank's local match arrays with the digest of that rank's rows in the gathered arrays
     # (what arrived is what was computed).  Any mismatch on any rank: no value.
     from oracle import ora
-    from oracle_check import blocks_for, check_pass, compare_block, oracle_block
+    from oracle_check import blocks_for, check_pass, compare_block
     if rank == 0:
         ora.lib()                 # (re)builds oracle/_build/liboracle.so if its sources are newer: one rank only, the others load it after
     if world > 1:
@@ -765,53 +765,26 @@ def main():
     parity["checked"] = "keypoint indices, scores, descriptors, intensities, match counts, match pairs, match quality"
     parity["frames_total"], parity["pairs_total"] = n * world, n * world - cfg.spacing
     if world > 1:
-        import hashlib
-
-        def digest(mt, q, c):
-            hsh = hashlib.sha256()
-            for t_ in (mt, q, c):
-                hsh.update(t_.contiguous().cpu().numpy().tobytes())
-            return hsh.hexdigest()
-
-        mine = dict(parity, rank=rank, digest=digest(out["matches"], out["quality"], out["match_count"]))
+        from oracle_check import check_boundaries, check_gathered_rows, digest_matches, merge_rank_reports
+        mine = dict(parity, rank=rank, digest=digest_matches(out["matches"], out["quality"], out["match_count"]))
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         if rank == 0:
-            sp_ = cfg.spacing
-            merged = dict(parity, frames_checked_vs_oracle=0, pairs_checked=0, matches_checked=0)
-            for pr in per_rank:
-                for k_ in ("frames_checked_vs_oracle", "pairs_checked", "matches_checked"):
-                    merged[k_] += pr[k_]
-                if not pr["bit_exact"]:
-                    merged["bit_exact"] = False
-                    merged["first_mismatch"] = merged["first_mismatch"] or f"rank {pr['rank']}: {pr['first_mismatch']}"
-            # boundary pairs of the gathered result against the oracle on regenerated frames
+            merged = merge_rank_reports(per_rank)
             gm = {"matches": out["all_matches"], "quality": out["all_quality"], "match_count": out["all_match_count"]}
-            bpairs = bmatches = 0
             if args.test_corrupt_gathered:
-                row_ = ranges[1][0] - sp_
+                row_ = ranges[1][0] - cfg.spacing
                 gm["matches"][row_, 0, 1] = (gm["matches"][row_, 0, 1] + 1) % K
-            for r_ in range(1, world):
-                b_ = ranges[r_][0]
-                bi, bt = synth_sequence(n * world, b_ - sp_, b_ + sp_, h, w, grid, dev, seed=1234)
-                ob = oracle_block(bi.cpu().numpy(), bt.cpu().numpy(), ssd, rsd, size, K, cfg)
-                rows = {k_: v_[b_ - sp_:b_].cpu().numpy() for k_, v_ in gm.items()}
-                okb, _, np_, nm_, why = compare_block(ob, {}, rows, 0, K)
-                bpairs += np_
-                bmatches += nm_
-                if not okb:
-                    merged["bit_exact"] = False
-                    merged["first_mismatch"] = merged["first_mismatch"] or f"boundary of rank {r_} (frame {b_}): {why}"
-            # what arrived on rank 0 is what every rank computed
-            off_, same_rows = 0, True
-            for r_, pr in enumerate(per_rank):
-                np_r = out["pairs_per_rank"][r_]
-                same_rows = same_rows and digest(gm["matches"][off_:off_ + np_r], gm["quality"][off_:off_ + np_r],
-                                                 gm["match_count"][off_:off_ + np_r]) == pr["digest"]
-                off_ += np_r
-            if not same_rows:
+
+            def regen(a_, b_):          # frames [a_, b_) of the one sequence, from the seed (on this rank's GPU, then to the host)
+                bi, bt = synth_sequence(n * world, a_, b_, h, w, grid, dev, seed=1234)
+                return bi.cpu().numpy(), bt.cpu().numpy()
+
+            okb, bpairs, bmatches, whyb = check_boundaries(gm, [ranges[r_][0] for r_ in range(1, world)], regen, ssd, rsd, size, K, cfg)
+            same_rows = check_gathered_rows(gm, out["pairs_per_rank"], [pr["digest"] for pr in per_rank])
+            if not okb or not same_rows:
                 merged["bit_exact"] = False
-                merged["first_mismatch"] = merged["first_mismatch"] or "gathered rows differ from a rank's local match arrays"
+                merged["first_mismatch"] = merged["first_mismatch"] or whyb or "gathered rows differ from a rank's local match arrays"
             merged.update(boundary_pairs_checked=bpairs, boundary_matches_checked=bmatches, boundaries=world - 1,
                           gathered_rows_equal_every_ranks_local_result=same_rows, ranks_checked=world)
             merged["pairs_checked"] += bpairs

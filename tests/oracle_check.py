@@ -105,3 +105,60 @@ def check_pass(out: dict, imgs, toks, ssd: dict, rsd: dict, size: int, K: int, c
             tot["first_mismatch"] = f"frames [{frame0 + a}, {frame0 + b}): {why}"
             break
     return tot
+
+
+# ----------------------------------------------------------------------------------------- the gate of an N-rank run (bench.py)
+def digest_matches(matches, quality, match_count) -> str:
+    """SHA-256 of a rank's match arrays (torch tensors, any device): what a rank computed, to be compared with its rows of the
+    gathered arrays on rank 0."""
+    import hashlib
+    h = hashlib.sha256()
+    for t in (matches, quality, match_count):
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def merge_rank_reports(per_rank: list) -> dict:
+    """check_pass results of every rank (each with a 'rank' key) -> one report: counts added, the first mismatch named by rank."""
+    merged = dict(per_rank[0], frames_checked_vs_oracle=0, pairs_checked=0, matches_checked=0, bit_exact=True, first_mismatch=None)
+    for pr in per_rank:
+        for k in ("frames_checked_vs_oracle", "pairs_checked", "matches_checked"):
+            merged[k] += pr[k]
+        if not pr["bit_exact"]:
+            merged["bit_exact"] = False
+            merged["first_mismatch"] = merged["first_mismatch"] or f"rank {pr['rank']}: {pr['first_mismatch']}"
+    merged.pop("rank", None)
+    merged.pop("digest", None)
+    return merged
+
+
+def check_boundaries(gathered: dict, boundaries: list, regen, ssd: dict, rsd: dict, size: int, K: int, cfg) -> tuple:
+    """The pairs that cross a shard boundary - the only ones that exercise the halo exchange and the in-place gather - through
+    the GATHERED arrays: for every boundary frame b (the first frame of a rank > 0), regen(b - spacing, b + spacing) returns the
+    (images, tokens) numpy arrays of those frames, the oracle runs on them, and rows b - spacing .. b - 1 of gathered
+    ['matches' | 'quality' | 'match_count'] (row = the sequence's pair number = its first frame) must equal the oracle's pairs.
+    Returns (ok, pairs, matches, first mismatch or None)."""
+    sp = cfg.spacing
+    pairs = nm = 0
+    for r, b in enumerate(boundaries, start=1):
+        im, tk = regen(b - sp, b + sp)
+        o = oracle_block(im, tk, ssd, rsd, size, K, cfg)
+        rows = {k: gathered[k][b - sp:b].cpu().numpy() for k in ("matches", "quality", "match_count")}
+        ok, _, np_, nm_, why = compare_block(o, {}, rows, 0, K)
+        pairs += np_
+        nm += nm_
+        if not ok:
+            return False, pairs, nm, f"boundary of rank {r} (frame {b}): {why}"
+    return True, pairs, nm, None
+
+
+def check_gathered_rows(gathered: dict, pairs_per_rank: list, digests: list) -> bool:
+    """What arrived on rank 0 is what every rank computed: the digest of rank r's rows of the gathered arrays == the digest rank
+    r took of its local match arrays."""
+    off = 0
+    for npairs, d in zip(pairs_per_rank, digests):
+        sl = slice(off, off + npairs)
+        if digest_matches(gathered["matches"][sl], gathered["quality"][sl], gathered["match_count"][sl]) != d:
+            return False
+        off += npairs
+    return True

@@ -75,3 +75,42 @@ def test_block_plans(n, want, sp):
         frames = sum(b - a for a, b in blocks)
         assert frames >= want - 2 and len(pairs) >= frames - 3 * sp
         assert blocks[0][0] == 0 and blocks[-1][1] == n                  # both ends
+
+
+def test_n_rank_gate_pieces_on_a_two_shard_split():
+    """The rank-0 side of bench.py's N > 1 gate, on arrays assembled from the oracle (no GPU, no process group): a 7-frame
+    sequence cut 4 | 3.  The boundary pair (frames 3 | 4) is checked through the 'gathered' arrays against the oracle on
+    regenerated frames; the gathered rows of each rank against the digest of what that rank 'computed'; per-rank reports are
+    merged.  One flipped index in the boundary row, one gathered row that differs from its sender's - each is refused and named."""
+    from oracle_check import check_boundaries, check_gathered_rows, digest_matches, merge_rank_reports
+    cfg = _Cfg()
+    cfg.spacing = 1
+    n, K, cut = 7, 500, 4
+    ssd, rsd = synth.selector_state(0), synth.refiner_state(0)
+    toks, imgs = synth.token_sequence(n, 28), synth.image_sequence(n)
+    whole = _padded(oracle_block(imgs, toks, ssd, rsd, 448, K, cfg), K, 1)            # 6 pairs: rows 0..5
+    gathered = {k: whole[k] for k in ("matches", "quality", "match_count")}
+    regen = lambda a, b: (imgs[a:b], toks[a:b])                                        # noqa: E731
+    ok, pairs, nm, why = check_boundaries(gathered, [cut], regen, ssd, rsd, 448, K, cfg)
+    assert ok and pairs == 1 and nm == int(whole["match_count"][cut - 1]) and why is None
+    # rank 0 computed pairs 0..3 (its 4 frames + the halo frame), rank 1 pairs 4..5
+    ppr = [cut, n - 1 - cut]
+    local = [{k: gathered[k][:cut] for k in gathered}, {k: gathered[k][cut:] for k in gathered}]
+    digs = [digest_matches(m["matches"], m["quality"], m["match_count"]) for m in local]
+    assert check_gathered_rows(gathered, ppr, digs)
+    rep = merge_rank_reports([dict(frames_checked_vs_oracle=4, pairs_checked=3, matches_checked=10, bit_exact=True, first_mismatch=None, rank=0, digest=digs[0]),
+                              dict(frames_checked_vs_oracle=3, pairs_checked=2, matches_checked=7, bit_exact=True, first_mismatch=None, rank=1, digest=digs[1])])
+    assert rep["bit_exact"] and rep["frames_checked_vs_oracle"] == 7 and rep["pairs_checked"] == 5 and "digest" not in rep
+    rep = merge_rank_reports([dict(frames_checked_vs_oracle=4, pairs_checked=3, matches_checked=10, bit_exact=True, first_mismatch=None, rank=0),
+                              dict(frames_checked_vs_oracle=1, pairs_checked=0, matches_checked=0, bit_exact=False, first_mismatch="frames [4, 7): idx differs at block frame 0", rank=1)])
+    assert not rep["bit_exact"] and rep["first_mismatch"].startswith("rank 1: ")
+    # a flipped index in the boundary row
+    bad = {k: v.clone() for k, v in gathered.items()}
+    bad["matches"][cut - 1, 0, 1] = (bad["matches"][cut - 1, 0, 1] + 1) % K
+    ok, _, _, why = check_boundaries(bad, [cut], regen, ssd, rsd, 448, K, cfg)
+    assert not ok and "boundary of rank 1 (frame 4)" in why
+    assert not check_gathered_rows(bad, ppr, digs)                       # ... which is also not what rank 0 sent
+    # a row of rank 1's block changed in transit: the boundary check cannot see it, the digest does
+    bad = {k: v.clone() for k, v in gathered.items()}
+    bad["quality"][n - 2, 0] += 1.0
+    assert check_boundaries(bad, [cut], regen, ssd, rsd, 448, K, cfg)[0] and not check_gathered_rows(bad, ppr, digs)
