@@ -19,6 +19,13 @@ scripts themselves and `configs/train_config.yaml` are the reference's files, un
         backward, clip_grad_norm_, optimizer.step), validate, save_checkpoint('best_model.pth').
   (iii) SequenceMatcher again, on the checkpoint train.py just wrote, with the in-repo ViT (random weights) inside: extract +
         match run end to end from a PNG.
+  (iv)  the other callers of the path, each through its own constructor (YAML + that checkpoint) and its own entry on the synthetic
+        TUM directory: visualize_matches.MatchVisualizer.extract_features / find_matches (M2; :70-124), and the four evaluation
+        classes of test/*.py, which call backbone.eval() (eval-mode BatchNorm): TrackingTester.track_frame_sequence
+        (M5; test_tracking.py:87-197), DescriptorQualityTester.test_sequence (M4 + the pose-derived ground truth;
+        test_descriptor_quality.py:233-305), RepeatabilityTester.test_sequence (test_repeatability.py:130-216),
+        PerformanceTester.measure_component_times (the reference's timing protocol; test_performance.py:78-144).  Their
+        matchers' outputs are compared with the CPU oracle's M2 / M4 / M5 on the same descriptors (matching.py is HIP-only).
 
 Third-party modules absent from this image: `torchvision.transforms` is given a PIL stand-in (Resize / ToTensor / Normalize /
 Compose - what torchvision does for a PIL input), `cv2` / `wandb` / `timm` inert placeholders (unused on these paths: wandb is
@@ -250,12 +257,82 @@ def part_train_then_match(tmp: str) -> dict:
                                  f1["intensity"], f2["intensity"], 0.15)
     assert f1["descriptors"].shape == (500, 128) and np.allclose(np.linalg.norm(f1["descriptors"], axis=1), 1.0, atol=1e-5)
     assert mt.ndim == 2 and mt.shape[1] == 2 and mt.dtype == np.int64 and q.shape == (mt.shape[0],)
-    return {"script": "train.py", "class": "SemanticSLAMTrainer", "device": "cpu", "batch": 4, "train_batches": 2, "val_batches": 1,
+    other = part_other_callers(tmp, ckpt, root, config)
+    return {"other_callers": other,
+            "script": "train.py", "class": "SemanticSLAMTrainer", "device": "cpu", "batch": 4, "train_batches": 2, "val_batches": 1,
             "first_step_loss": float(loss), "loss_components": {k: float(v) for k, v in comps.items()},
             "first_step_matches_per_sample_padded": int(metrics["num_matches"]),
             "grad_abs_sum_selector": gsel, "grad_abs_sum_refiner": gref, "parameter_tensors_moved": f"{changed} / {len(before)}",
             "checkpoint_keys": sorted(sd), "best_val_loss": float(sd["loss"]),
             "then_visualize_matches_sequence_on_that_checkpoint": {"frames": 2, "matches": int(len(mt)), "vit": "in-repo DINOv3 ViT-S/16, random weights, eager fp32 on cpu"}}
+
+
+# ---------------------------------------------------------------------------------------------- (iv)
+def part_other_callers(tmp: str, ckpt: str, root: str, config: dict) -> dict:
+    import torch
+    import yaml
+
+    from oracle import ora               # the CPU oracle's M2 / M4 / M5 (matching.py itself is HIP-only: no GPU in this container)
+    sys.path.insert(2, os.path.join(REF, "test"))
+    import test_descriptor_quality as tdq
+    import test_performance as tperf
+    import test_repeatability as trep
+    import test_tracking as ttrack
+    import visualize_matches as vm
+    for mod in (tdq, tperf, trep, ttrack, vm):
+        assert os.path.realpath(mod.__file__).startswith("/root/reference/"), mod.__file__
+    cfg_path = os.path.join(tmp, "eval_config.yaml")            # the reference's YAML with the data paths of this run (a temp file)
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(config, f)
+    seq = "rgbd_dataset_synth_train"
+    rgb = os.path.join(root, seq, "rgb")
+    files = sorted(os.listdir(rgb))
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # visualize_matches.py: M2 (ratio test against the runner-up by masking the best column)
+        mv = vm.MatchVisualizer(ckpt, cfg_path, device="cpu")
+        f1, f2 = mv.extract_features(os.path.join(rgb, files[0])), mv.extract_features(os.path.join(rgb, files[1]))
+        m2 = mv.find_matches(f1["descriptors"], f2["descriptors"], ratio_thresh=0.8)
+        mine = ora.find_matches_m2(f1["descriptors"], f2["descriptors"], ratio_thresh=0.8)
+        assert [(i, j) for i, j, _ in m2] == [(i, j) for i, j, _ in mine], "M2: match pairs differ between the script and the oracle"
+        assert np.allclose([s for _, _, s in m2], [s for _, _, s in mine], atol=1e-5)
+        out["visualize_matches.MatchVisualizer"] = {"matches_M2": len(m2), "equal_to_oracle_M2": True}
+
+        # test_tracking.py: M5 (count of rows whose best similarity exceeds the threshold), eval-mode backbone
+        tt = ttrack.TrackingTester(ckpt, cfg_path, device="cpu")
+        assert not tt.backbone.training and not tt.backbone.feature_norm.training
+        r = tt.track_frame_sequence(seq, max_frames=4, min_matches=50, match_threshold=0.8, frame_spacing=1)
+        assert r["total_frames"] == 2 and len(r["match_counts"]) == 2        # 4 frames: len(dataset) = 3, the loop visits frames 1 and 2
+        ds = ttrack.TUMDataset(dataset_root=root, sequence=seq, input_size=448, frame_spacing=1, max_frames=4, augmentation=None, is_train=False)
+        d0 = tt.extract_features(ds[0]["rgb1"].unsqueeze(0))[1]
+        d1 = tt.extract_features(ds[1]["rgb1"].unsqueeze(0))[1]
+        assert int(r["match_counts"][0]) == int((ora.sim_matrix(d0, d1).max(axis=1) > np.float32(0.8)).sum()), "M5: tracked count differs from the oracle"
+        out["test_tracking.TrackingTester"] = {"pairs": 2, "match_counts": [int(c) for c in r["match_counts"]], "equal_to_oracle_M5": True,
+                                               "tracking_success_rate": float(r["tracking_success_rate"])}
+
+        # test_descriptor_quality.py: M4 (mutual NN + ratio by full row sort) and the pose-derived ground truth
+        tq = tdq.DescriptorQualityTester(ckpt, cfg_path, device="cpu")
+        r = tq.test_sequence(seq, num_pairs=2, frame_spacing=1)
+        assert r["num_pairs"] == 2 and 0.0 <= r["mean_precision"] <= 1.0
+        pm, pd = tq.find_mutual_nearest_neighbors(d0, d1)
+        mm, md = ora.find_mnn_m4(d0, d1)
+        assert np.array_equal(np.asarray(pm), np.asarray(mm)) and np.allclose(pd, md, atol=1e-5), "M4 differs from the oracle"
+        out["test_descriptor_quality.DescriptorQualityTester"] = {"pairs": 2, "mean_num_matches": float(r["mean_num_matches"]),
+                                                                  "matches_M4_first_pair": int(len(pm)), "equal_to_oracle_M4": True}
+
+        # test_repeatability.py
+        tr = trep.RepeatabilityTester(ckpt, cfg_path, device="cpu")
+        r = tr.test_sequence(seq, num_pairs=2, frame_spacing=1, use_pose=True)
+        assert r["num_pairs"] == 2 and 0.0 <= r["mean_repeatability"] <= 1.0
+        out["test_repeatability.RepeatabilityTester"] = {"pairs": 2, "mean_repeatability": float(r["mean_repeatability"])}
+
+        # test_performance.py: the reference's stage timers (10 warm-up + num_runs timed forward passes of one image)
+        tp = tperf.PerformanceTester(ckpt, cfg_path, device="cpu")
+        times = tp.measure_component_times(ds[0]["rgb1"].unsqueeze(0), num_runs=2)
+        assert set(times) >= {"backbone", "selector", "selector_nms", "refiner", "total"} and times["total"]["mean"] > 0
+        out["test_performance.PerformanceTester"] = {"stages": sorted(times), "total_ms_cpu_eager": float(times["total"]["mean"])}
+    return out
 
 
 def main():
