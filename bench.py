@@ -216,8 +216,8 @@ def main():
     ap.add_argument("--sustain", type=float, default=10.0, help="N = 1: seconds of back-to-back steps for the `sustained` rate (0: skip)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (profiling runs)")
     ap.add_argument("--parity-frames", type=int, default=-1,
-                    help="frames per rank compared with the CPU oracle after the timed region (-1: the whole block at G = 28, "
-                         "258 frames in three blocks at the larger grids)")
+                    help="frames per rank compared with the CPU oracle after the timed region (-1, the default: the whole block; "
+                         "a smaller count: that many frames in three blocks from both ends and the middle)")
     ap.add_argument("--no-vit", action="store_true", help="skip the additional end-to-end leg that includes the HIP ViT (A1)")
     ap.add_argument("--no-vit-fp32", action="store_true", help="skip the fp32-operand HIP ViT leg (reference numerics for A1) of the ViT-inside pass")
     ap.add_argument("--no-bf16", action="store_true", help="skip the additional bf16 throughput-mode leg (BASELINE configs[1])")
@@ -746,7 +746,7 @@ def main():
     # The metric says "match-index bit-exact vs CPU ref": the last timed step's outputs are compared with the CPU oracle, bit for
     # bit - keypoint indices, scores, descriptors, intensities of every checked frame, and for every checked pair the match count,
     # the match pairs and the quality (visualize_matches_sequence.py:106-197 with the CLI thresholds :381-388, the pair loop
-    # :297-320).  N = 1: the WHOLE sequence where the oracle covers it in seconds (G = 28: 613 frames ~ 3 s on 16 threads), else
+    # :297-320).  N = 1: the WHOLE sequence (613 frames at G = 28: ~3 s of oracle time on 16 threads; 2 965 at G = 40: 28 s), or
     # --parity-frames frames in blocks from both ends and the middle.  N > 1: every rank checks ITS block the same way on its
     # share of the host cores; rank 0 also regenerates the frames on either side of every shard boundary from the seed, runs
     # the oracle on them and compares the boundary pairs' rows of the GATHERED result (the only pairs that exercise the halo),
@@ -759,7 +759,8 @@ def main():
     if world > 1:
         dist.barrier()
     ora.set_num_threads(max(1, ora.host_threads() // world))
-    want = args.parity_frames if args.parity_frames >= 0 else (n if grid <= 28 and n <= 1400 else 258)
+    # default: the whole block (the oracle covers the largest workload, 2 965 frames at G = 40, in 28 s on 16 host threads)
+    want = args.parity_frames if args.parity_frames >= 0 else n
     tpar = time.perf_counter()
     parity = check_pass(out, imgs, toks, ssd, rsd, size, K, cfg, blocks_for(n, want, cfg.spacing), frame0=lo)
     parity["checked"] = "keypoint indices, scores, descriptors, intensities, match counts, match pairs, match quality"

@@ -62,6 +62,12 @@ def lib():
         _lib.ora_sigmoid.restype = C.c_float
         _lib.ora_sigmoid.argtypes = [C.c_float]
         _lib.ora_match_with_quality.restype = C.c_int
+        # an OpenMP runtime that another library initialised first (torch: one thread per LOGICAL cpu, 256 on the GPU box) ignores
+        # the environment default above: cap the team at what this process may really use (16 there), or every parallel region
+        # runs 256 threads on 16 CPUs - ten times slower
+        n = host_threads()
+        if _lib.ora_num_threads() > n:
+            _lib.ora_set_num_threads(C.c_int(n))
     return _lib
 
 
