@@ -61,6 +61,16 @@ struct EpiPatch {             // x[frame][5 + patch] = acc + bias
                 }
             }
     }
+    // the one-tile wave of the few-frame launch shape: acc[0][0] is rows m0 + crow(e, h), column n0 + r
+    __device__ __forceinline__ void one_tile(const f32x16 &acc, long long m0, int n0, int r, int h, long long M) const {
+        const float b0 = b[n0 + r];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const unsigned row = (unsigned)(m0 + crow(e, h));
+            const unsigned f = row / (unsigned)cells;
+            if (row < M) x[((long long)f * T + FPREFIX + (row - f * cells)) * FD + n0 + r] = acc[e] + b0;
+        }
+    }
 };
 // ---- epilogues of the per-layer GEMM (gemm_f32_rows_kernel evaluates the product TRANSPOSED: weights = A operand) ---------------
 // acc layout there: register e of lane (r, h) in tile (ni, ri) is column n0 + 32 ni + crow(e, h) of row m0 + 32 ri + r - a lane owns
@@ -264,11 +274,75 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(ALoad al, const float 
     epi(acc, m0 + wm * 64, n0 + wn * 64, r, h, M);
 }
 
+// The same GEMM on 32-row workgroups (four waves side by side, one 32 x 32 tile each): the launch shape for a FEW frames.  One frame's
+// patch embedding is 7 x 3 workgroups of the form above, each walking 24 k tiles of 64 MFMAs per wave behind two barriers - 60 us
+// on 21 CUs whatever the batch; here it is 25 x 3 workgroups of 16 MFMAs per wave and k tile.  Same k order per output: identical bits.
+template <class ALoad, class Epi>
+__global__ __launch_bounds__(256, 3) void gemm_f32_small_kernel(ALoad al, const float *__restrict__ W, int K, long long M, int ntn, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float As[32 * GLDK], Ws[GBN * GLDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const long long m0 = (long long)(blockIdx.x / ntn) * 32;
+    const int n0 = (blockIdx.x % ntn) * GBN;
+    const int srow = tid >> 2, sg = tid & 3;          // A: rows 0..31 (threads 0..127); W: rows srow and 64 + srow
+    long long ar0 = m0 + (srow & 31);
+    if (ar0 > M - 1) ar0 = M - 1;
+    float4 pa[2], pw[4];
+    auto fetch = [&](int k0) {
+        const float *a0 = al.at(ar0, k0 + 8 * sg);
+        const float *w0 = W + (long long)(n0 + srow) * K + k0 + 8 * sg, *w1 = W + (long long)(n0 + 64 + srow) * K + k0 + 8 * sg;
+        pa[0] = *reinterpret_cast<const float4 *>(a0);
+        pa[1] = *reinterpret_cast<const float4 *>(a0 + 4);
+        pw[0] = *reinterpret_cast<const float4 *>(w0);
+        pw[1] = *reinterpret_cast<const float4 *>(w0 + 4);
+        pw[2] = *reinterpret_cast<const float4 *>(w1);
+        pw[3] = *reinterpret_cast<const float4 *>(w1 + 4);
+    };
+    auto stash = [&]() {
+        float4 ev, od;
+        if (tid < 128) {
+            kp8_split(pa[0], pa[1], ev, od);
+            *reinterpret_cast<float4 *>(As + srow * GLDK + 8 * sg) = ev;
+            *reinterpret_cast<float4 *>(As + srow * GLDK + 8 * sg + 4) = od;
+        }
+        kp8_split(pw[0], pw[1], ev, od);
+        *reinterpret_cast<float4 *>(Ws + srow * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(Ws + srow * GLDK + 8 * sg + 4) = od;
+        kp8_split(pw[2], pw[3], ev, od);
+        *reinterpret_cast<float4 *>(Ws + (64 + srow) * GLDK + 8 * sg) = ev;
+        *reinterpret_cast<float4 *>(Ws + (64 + srow) * GLDK + 8 * sg + 4) = od;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    fetch(0);
+    stash();
+    __syncthreads();
+    const float *Ar = As + r * GLDK + 4 * h, *Wr = Ws + (wave * 32 + r) * GLDK + 4 * h;
+    for (int k0 = 0; k0 < K; k0 += GBK) {
+        fetch(min(k0 + GBK, K - GBK));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ar + 8 * g), b0 = *reinterpret_cast<const f32x4 *>(Wr + 8 * g);
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) acc = mfma32(a0[sx], b0[sx], acc);
+        }
+        __syncthreads();
+        stash();
+        __syncthreads();
+    }
+    epi.one_tile(acc, m0, n0 + wave * 32, r, h, M);
+}
+
 template <class ALoad, class Epi>
 int launch_gemm(ALoad al, const float *W, int K, long long M, int N, Epi epi, hipStream_t st) {
     const int ntn = N / GBN;
     const long long blocks = (M + GBM - 1) / GBM * ntn;
-    hipLaunchKernelGGL((gemm_f32_kernel<ALoad, Epi>), dim3((unsigned)blocks), dim3(256), 0, st, al, W, K, M, ntn, epi);
+    if (blocks < 192) {          // a few frames: fewer 128-row workgroups than a quarter of the chip's slots - 32-row workgroups
+        hipLaunchKernelGGL((gemm_f32_small_kernel<ALoad, Epi>), dim3((unsigned)((M + 31) / 32 * ntn)), dim3(256), 0, st, al, W, K, M, ntn, epi);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<ALoad, Epi>), dim3((unsigned)blocks), dim3(256), 0, st, al, W, K, M, ntn, epi);
+    }
     sslam_count_launches(1);
     return hipGetLastError() == hipSuccess ? SSLAM_OK : SSLAM_E_LAUNCH;
 }

@@ -181,7 +181,7 @@ class HipViTF32:
         the other on the caller's stream (n_streams = 2: alternating between two side streams as HipViT does - measured slower
         here, see __init__); the caller's stream semantics are kept either way.
         The attention's launch form follows the size of the BATCH, not of a launch group: up to 8 frames (the reference's own
-        callers: B = 1, B = 4) the few-frame form (include/sslam_hip.h: key-split attention, K-quartered down projection; 1.83 -> 1.14 ms
+        callers: B = 1, B = 4) the few-frame form (include/sslam_hip.h: key-split attention, K-quartered down projection; 1.83 -> 1.11 ms
         for one frame), above it the one-pass
         form for every group, a short last one included - so a frame's tokens do not depend on where a batch is cut.
         batch_frames: the size of the batch these frames belong to when the caller itself hands it over in pieces
